@@ -1,0 +1,114 @@
+/* nbe.h -- C ABI of the MI355X-native N-body emulator engine (libnbe.so).
+ *
+ * The reference (oleg-savchenko/jax_nbody_emulator_with_dj) has no native/FFI boundary: its boundary is
+ * the Python API.  Each entry point below names the reference interface it replaces (file:line relative
+ * to the reference repository root); the Python shim in jax_nbody_emulator_with_dj_amd/ binds them with
+ * ctypes.
+ *
+ * Conventions: every function returns 0 on success and a non-zero code on failure; the message is
+ * available from nbe_last_error() (thread local).  Tensors are float32, C-contiguous, channel-first
+ * ((C, D, H, W)) exactly as the reference passes them.  Data pointers may be host OR device pointers
+ * (detected with hipPointerGetAttributes); the caller owns them.  The library owns all device memory it
+ * allocates.  One in-flight call per context; several contexts may coexist (one per GPU / stream).
+ */
+#ifndef NBE_H
+#define NBE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbe_ctx nbe_ctx;
+
+/* progress callback of nbe_process_box: replaces the tqdm bar of src/jax_nbody_emulator/subbox.py:186-193 */
+typedef void (*nbe_progress_cb)(int done, int total, void* user);
+
+/* One convolution layer of the parameter tree {'params': {block: {layer: {...}}}}
+ * (leaf shapes: tests/test_style_nbody_emulator_vel_core.py:408-419, style_layers_vel.py:55-75;
+ *  premodulated leaves: nbody_emulator.py:256-260).  All pointers are HOST float32. */
+typedef struct nbe_layer_desc {
+    const char* block;          /* "conv_l00", "down_l0", ...                         */
+    const char* layer;          /* "skip", "conv_0", "conv_1"                           */
+    int cout, cin, k;           /* weight shape (cout, cin, k, k, k)                    */
+    const float* weight;        /* style: raw weight; premodulated: normalised weight   */
+    const float* bias;          /* (cout,)                                              */
+    const float* style_weight;  /* (cin, 2)  -- style trees only                        */
+    const float* style_bias;    /* (cin,)    -- style trees only                        */
+    const float* dweight;       /* premodulated velocity trees only, same shape as weight */
+} nbe_layer_desc;
+
+enum { NBE_F32 = 0, NBE_F16 = 1 };
+
+const char* nbe_last_error(void);
+int nbe_version(void);
+
+/* context = one GPU + one stream + weights + workspace.
+ * replaces: the implicit JAX device/jit state created by SubboxProcessor.__init__ (subbox.py:106-137) */
+int nbe_create(int device_id, nbe_ctx** out);
+int nbe_destroy(nbe_ctx* ctx);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
+int nbe_set_stream(nbe_ctx* ctx, void* hip_stream);
+int nbe_synchronize(nbe_ctx* ctx);
+
+/* model hyper-parameters: StyleNBodyEmulatorVelCore(style_size=2, in_chan, out_chan, mid_chan, eps)
+ * (style_nbody_emulator_vel_core.py:39-43); compute_vel selects the *VelCore / *Core twin
+ * (nbody_emulator.py:324-339). */
+int nbe_set_arch(nbe_ctx* ctx, int in_chan, int out_chan, int mid_chan, float eps, int compute_vel);
+
+/* replaces model.apply's `params` argument for the Style* cores (README.md:155; subbox.py:224-233) */
+int nbe_load_style_weights(nbe_ctx* ctx, const nbe_layer_desc* layers, int nlayers);
+/* replaces `params` of the premodulated cores: output of modulate_emulator_parameters[_vel]
+ * (nbody_emulator.py:150-187, :221-266) */
+int nbe_load_premod_weights(nbe_ctx* ctx, const nbe_layer_desc* layers, int nlayers);
+
+/* Style cores: (Om, Dz) -> style vector s = ((Om-0.3)*5, Dz-1) and the per-layer weight modulation,
+ * demodulation and d/dDz (style_nbody_emulator_vel_core.py:126-128, style_layers_vel.py:62-105).
+ * Runs the modulate + pack kernels.  No-op for premodulated weights. */
+int nbe_set_cosmology(nbe_ctx* ctx, float Om, float Dz);
+
+/* model.apply(params, x[None], Om, Dz, vel_fac) for ONE batch element
+ * (style_nbody_emulator_vel_core.py:105-195 and the three sibling signatures, subbox.py:224-233).
+ * x: (in_chan, D, H, W); disp / vel: (out_chan, D-96, H-96, W-96); vel may be NULL when compute_vel=0. */
+int nbe_forward(nbe_ctx* ctx, const void* x, int D, int H, int W, float Dz, float vel_fac,
+                void* disp, void* vel);
+
+/* SubboxProcessor.process_box (subbox.py:139-219): periodic 48-voxel-halo crops of `box`
+ * ((in_chan, size0, size1, size2)), forward, ASSIGNMENT of the un-padded result into disp / vel
+ * ((in_chan, size...), out_dtype NBE_F32 or NBE_F16).  Dz, vel_fac: growth_factor / vel_norm scalars
+ * (subbox.py:173-178).  pad must be 48 on every side (the model's receptive field, subbox.py:43). */
+int nbe_process_box(nbe_ctx* ctx, const void* box, const int64_t size[3], const int ndiv[3], const int pad[6],
+                    float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
+                    nbe_progress_cb cb, void* user);
+
+/* growth_factor / vel_norm (cosmology.py:34-40, :130-141) in double precision on the host. */
+double nbe_growth_factor(double z, double Om);
+double nbe_vel_norm(double z, double Om);
+
+/* ---- test / measurement hooks (not part of the reference surface) ------------------------------ */
+
+/* One layer through the production kernels, host NCDHW in / out.  kind: 0 conv3 (VALID 3x3x3),
+ * 1 skip (1x1x1, centre-cropped by `crop`), 2 down (k2 s2), 3 up (k2, lhs_dilation 2).
+ * flags: 1 = LeakyReLU, 2 = add residual (res/dres shaped like the output).  dx/dw/dy/dres may be NULL. */
+int nbe_test_layer(nbe_ctx* ctx, int kind, int crop, int flags, const float* x, const float* dx, int cin,
+                   int D, int H, int W, const float* w, const float* dw, const float* bias, int cout,
+                   const float* res, const float* dres, float* y, float* dy);
+/* modulation kernel alone: OIDHW weight -> (w_n, dw_tot) */
+int nbe_test_modulate(nbe_ctx* ctx, const float* weight, const float* style_weight, const float* style_bias,
+                      int cout, int cin, int k, float s0, float s1, float eps, int first_layer,
+                      float* w_n, float* dw_tot);
+
+/* per-kernel HIP-event timing on the engine's stream (bench.py roofline leg) */
+int nbe_profile_enable(nbe_ctx* ctx, int on);
+int nbe_profile_reset(nbe_ctx* ctx);
+int nbe_profile_count(nbe_ctx* ctx);
+/* entry i: kernel name, summed device ms, launches, algorithmic FLOPs (2*MAC of valid outputs) */
+int nbe_profile_entry(nbe_ctx* ctx, int i, char* name, int name_cap, double* ms, int64_t* launches, double* flops);
+/* bytes of device workspace currently held */
+int64_t nbe_workspace_bytes(nbe_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBE_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of libnbe.so (C ABI: include/nbe.h).
+
+The library is built in-tree by `build()` (hipcc, gfx950 only).  There is no CPU
+fallback anywhere in this package: if the shared object is missing, or no MI355X
+is visible, the product path raises.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbe.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ("nbe_kernels.hip", "nbe_engine.cpp")
+
+
+class NBEError(RuntimeError):
+    pass
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [
+        ("block", C.c_char_p), ("layer", C.c_char_p),
+        ("cout", C.c_int), ("cin", C.c_int), ("k", C.c_int),
+        ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("style_weight", C.c_void_p), ("style_bias", C.c_void_p),
+        ("dweight", C.c_void_p),
+    ]
+
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_void_p)
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol of include/nbe.h
+SIGNATURES = {
+    "nbe_last_error": (C.c_char_p, []),
+    "nbe_version": (C.c_int, []),
+    "nbe_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nbe_destroy": (C.c_int, [C.c_void_p]),
+    "nbe_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nbe_synchronize": (C.c_int, [C.c_void_p]),
+    "nbe_set_arch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "nbe_load_style_weights": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), C.c_int]),
+    "nbe_load_premod_weights": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), C.c_int]),
+    "nbe_set_cosmology": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
+    "nbe_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                              C.c_void_p, C.c_void_p]),
+    "nbe_process_box": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                  PROGRESS_CB, C.c_void_p]),
+    "nbe_growth_factor": (C.c_double, [C.c_double, C.c_double]),
+    "nbe_vel_norm": (C.c_double, [C.c_double, C.c_double]),
+    "nbe_test_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nbe_test_modulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "nbe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "nbe_profile_reset": (C.c_int, [C.c_void_p]),
+    "nbe_profile_count": (C.c_int, [C.c_void_p]),
+    "nbe_profile_entry": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "nbe_workspace_bytes": (C.c_int64, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into libnbe.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "nbe_kernels.h"), os.path.join(_HERE, "..", "include", "nbe.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NBEError(
+                "libnbe.so is missing at %s. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NBEError(lib().nbe_last_error().decode("utf-8", "replace"))

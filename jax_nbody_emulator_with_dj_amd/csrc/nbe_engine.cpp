@@ -1,0 +1,806 @@
+// Engine behind the C ABI (include/nbe.h): weights, workspace planning, the U-Net schedule
+// (style_nbody_emulator_vel_core.py:105-195) and the sub-box loop (subbox.py:139-219).
+// Host code only; every device operation is a launch from nbe_kernels.hip.
+
+#include "../../include/nbe.h"
+#include "nbe_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace nbe;
+
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// workspace: first-fit allocator over one device block; a dry run sizes it
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    struct Blk { int64_t off, size; bool used; };
+    std::vector<Blk> blks;
+    int64_t high = 0;
+    void reset() { blks.clear(); blks.push_back({0, INT64_MAX / 2, false}); high = 0; }
+    int64_t alloc(int64_t bytes) {
+        bytes = (bytes + 255) & ~int64_t(255);
+        for (size_t i = 0; i < blks.size(); ++i) {
+            if (!blks[i].used && blks[i].size >= bytes) {
+                Blk rest{blks[i].off + bytes, blks[i].size - bytes, false};
+                blks[i].size = bytes; blks[i].used = true;
+                if (rest.size > 0) blks.insert(blks.begin() + i + 1, rest);
+                if (blks[i].off + bytes > high) high = blks[i].off + bytes;
+                return blks[i].off;
+            }
+        }
+        return -1;
+    }
+    void release(int64_t off) {
+        for (size_t i = 0; i < blks.size(); ++i) {
+            if (blks[i].off == off && blks[i].used) {
+                blks[i].used = false;
+                if (i + 1 < blks.size() && !blks[i + 1].used) { blks[i].size += blks[i + 1].size; blks.erase(blks.begin() + i + 1); }
+                if (i > 0 && !blks[i - 1].used) { blks[i - 1].size += blks[i].size; blks.erase(blks.begin() + i); }
+                return;
+            }
+        }
+    }
+};
+
+struct Layer {
+    std::string block, layer;
+    int cout = 0, cin = 0, k = 0, kind = 0;       // kind: 0 conv3, 1 skip, 2 down, 3 up
+    bool first = false;                           // conv_l00/{conv_0,skip}: input linear in Dz
+    float *weight = nullptr, *sw = nullptr, *sb = nullptr;   // raw style parameters (device)
+    float *wn = nullptr, *dwn = nullptr;          // modulated OIDHW (device)
+    PackedW pw;
+};
+
+struct ProfEntry { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
+
+struct nbe_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int in_chan = 3, out_chan = 3, mid = 64;
+    float eps = 1e-8f;
+    bool vel = true;
+    bool have_weights = false, style = false, modulated = false;
+    float mod_Om = NAN, mod_Dz = NAN;
+    std::map<std::string, Layer> layers;
+    // workspace
+    Arena arena;
+    char* ws = nullptr;
+    int64_t ws_bytes = 0;
+    bool dry = false;
+    // device-resident boxes of process_box
+    float* box_in = nullptr; int64_t box_in_bytes = 0;
+    char* box_out = nullptr; int64_t box_out_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    struct Pending { int entry; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+// ------------------------------------------------------------------------------------------------
+// cosmology scalars (cosmology.py:24-40, :101-141), double precision, own 2F1 series
+// ------------------------------------------------------------------------------------------------
+static double hyp2f1_series(double a, double b, double c, double z) {
+    double term = 1.0, sum = 1.0;
+    for (int n = 0; n < 200000; ++n) {
+        term *= (a + n) * (b + n) / ((c + n) * (n + 1.0)) * z;
+        sum += term;
+        if (std::fabs(term) < 1e-17 * std::fabs(sum)) break;
+    }
+    return sum;
+}
+static double hyp2f1(double a, double b, double c, double x) {
+    if (x < 0) return std::pow(1.0 - x, -a) * hyp2f1_series(a, c - b, c, x / (x - 1.0));   // Pfaff
+    return hyp2f1_series(a, b, c, x);
+}
+static const double A2 = 1.0, B2 = 1.0 / 3.0, C2 = 11.0 / 6.0;
+
+extern "C" double nbe_growth_factor(double z, double Om) {
+    const double a = 1.0 / (1.0 + z), OL = 1.0 - Om;
+    return a * hyp2f1(A2, B2, C2, -OL * a * a * a / Om) / hyp2f1(A2, B2, C2, -OL / Om);
+}
+static double growth_rate(double z, double Om) {
+    const double a = 1.0 / (1.0 + z), x = -(1.0 - Om) * a * a * a / Om;
+    const double F = hyp2f1(A2, B2, C2, x);
+    const double dF = (A2 * B2 / C2) * hyp2f1(A2 + 1, B2 + 1, C2 + 1, x);
+    return 1.0 + 3.0 * x * dF / F;
+}
+extern "C" double nbe_vel_norm(double z, double Om) {
+    const double H = 100.0 * std::sqrt(Om * std::pow(1.0 + z, 3) + (1.0 - Om));
+    return nbe_growth_factor(z, Om) * growth_rate(z, Om) * H / (1.0 + z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+static int roundup(int v, int m) { return (v + m - 1) / m * m; }
+static int planes_for(int C) { return roundup(C, 16) / 4; }     // every consumer reads whole 16-channel chunks at most
+
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice;
+}
+
+static Planes ws_planes(nbe_ctx* c, int G, int D, int H, int W, int64_t* off_out) {
+    Planes p;
+    p.G = G; p.D = D; p.H = H; p.W = W;
+    p.pstride = (p.vox() + 63) & ~int64_t(63);
+    const int64_t one = (int64_t)G * p.pstride * 16;
+    const int64_t off = c->arena.alloc(one * (c->vel ? 2 : 1));
+    *off_out = off;
+    if (!c->dry) {
+        p.x = (float*)(c->ws + off);
+        p.dx = c->vel ? (float*)(c->ws + off + one) : nullptr;
+    }
+    return p;
+}
+
+struct Tensor { Planes p; int64_t off = -1; };
+static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
+    Tensor t;
+    t.p = ws_planes(c, planes_for(C), D, H, W, &t.off);
+    return t;
+}
+static void tfree(nbe_ctx* c, Tensor& t) { if (t.off >= 0) c->arena.release(t.off); t.off = -1; }
+
+static int prof_entry(nbe_ctx* c, const std::string& name) {
+    for (size_t i = 0; i < c->prof_entries.size(); ++i) if (c->prof_entries[i].name == name) return (int)i;
+    c->prof_entries.push_back({name, 0, 0, 0});
+    return (int)c->prof_entries.size() - 1;
+}
+static hipEvent_t get_event(nbe_ctx* c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+static void prof_collect(nbe_ctx* c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        c->prof_entries[p.entry].ms += ms;
+        c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+static std::string conv_name(const PackedW& pw, bool vel, bool has_dx) {
+    const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
+    char b[96];
+    snprintf(b, sizeof b, "conv_mfma<%s,%s,%s,ni%d>", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx", pw.ni);
+    return b;
+}
+
+// launch one convolution layer (or record it in a dry run)
+static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl, bool has_dx) {
+    if (c->dry) return;
+    int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
+    if (c->prof) {
+        pe = prof_entry(c, conv_name(L.pw, c->vel, has_dx));
+        ea = get_event(c); eb = get_event(c);
+        (void)hipEventRecord(ea, c->stream);
+    }
+    launch_conv(L.pw, cl, c->vel, has_dx, c->stream);
+    if (c->prof) {
+        (void)hipEventRecord(eb, c->stream);
+        c->pending.push_back({pe, ea, eb});
+        // algorithmic FLOPs: 2*MAC over valid outputs; x3 with tangent (x2 when the input has no tangent)
+        const double nout = (double)cl.Dv * cl.Hv * cl.Wv;
+        const int taps = L.kind == 0 ? 27 : L.kind == 2 ? 8 : 1;
+        const double gemms = c->vel ? (has_dx ? 3.0 : 2.0) : 1.0;
+        c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.cin * taps * gemms;
+        c->prof_entries[pe].launches += 1;
+        if (c->pending.size() > 4096) prof_collect(c);
+    }
+}
+
+static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer) {
+    auto it = c->layers.find(std::string(block) + "/" + layer);
+    return it == c->layers.end() ? nullptr : &it->second;
+}
+
+// ------------------------------------------------------------------------------------------------
+// schedule
+// ------------------------------------------------------------------------------------------------
+
+// StyleResNetBlock3DVel (style_blocks_vel.py:96-166): skip 1x1x1 cropped by 2, conv-act-conv, add, [act]
+static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, bool final_act,
+                    int cout, int cmid, Tensor* out) {
+    const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
+    if (!Ls || !L0 || !L1) return fail("missing layers of block %s", name);
+    const int D = x.p.D, H = x.p.H, W = x.p.W;
+    Tensor s = talloc(c, cout, D - 4, H - 4, W - 4);
+    Tensor h = talloc(c, cmid, D - 2, H - 2, W - 2);
+    Tensor o = talloc(c, cout, D - 4, H - 4, W - 4);
+    if (s.off < 0 || h.off < 0 || o.off < 0) return fail("workspace exhausted in block %s", name);
+    {
+        ConvLaunch cl; cl.in = x.p; cl.in_off = (2L * H + 2) * W + 2;
+        cl.Dv = D - 4; cl.Hv = H - 4; cl.Wv = W - 4; cl.out = s.p; cl.flags = 0;
+        run_conv(c, *Ls, cl, has_dx);
+    }
+    {
+        ConvLaunch cl; cl.in = x.p; cl.Dv = D - 2; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = h.p; cl.flags = F_ACT;
+        run_conv(c, *L0, cl, has_dx);
+    }
+    {
+        ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = H - 4; cl.Wv = W - 4; cl.out = o.p;
+        cl.res = s.p; cl.flags = F_RES | (final_act ? F_ACT : 0);
+        run_conv(c, *L1, cl, true);
+    }
+    tfree(c, s); tfree(c, h);
+    *out = o;
+    return 0;
+}
+
+static int downblock(nbe_ctx* c, const char* name, const Tensor& x, Tensor* out) {
+    const Layer* L = find_layer(c, name, "conv_0");
+    if (!L) return fail("missing layer %s/conv_0", name);
+    Tensor o = talloc(c, c->mid, x.p.D / 2, x.p.H / 2, x.p.W / 2);
+    if (o.off < 0) return fail("workspace exhausted in %s", name);
+    ConvLaunch cl; cl.in = x.p; cl.Dv = o.p.D; cl.Hv = o.p.H; cl.Wv = o.p.W; cl.out = o.p; cl.flags = F_ACT;
+    run_conv(c, *L, cl, true);
+    *out = o;
+    return 0;
+}
+
+// up-sample into planes [mid/4, 2*mid/4) of the concat tensor (core :166-169: concat([skip, up]))
+static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& cat) {
+    const Layer* L = find_layer(c, name, "conv_0");
+    if (!L) return fail("missing layer %s/conv_0", name);
+    if (cat.p.D != 2 * x.p.D || cat.p.H != 2 * x.p.H || cat.p.W != 2 * x.p.W)
+        return fail("internal: concat geometry mismatch in %s", name);
+    for (int p = 0; p < 8; ++p) {
+        ConvLaunch cl; cl.in = x.p; cl.Dv = x.p.D; cl.Hv = x.p.H; cl.Wv = x.p.W; cl.out = cat.p;
+        cl.out_g0 = c->mid / 4; cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
+        cl.flags = F_ACT; cl.set = p;
+        run_conv(c, *L, cl, true);
+    }
+    return 0;
+}
+
+static void crop_into(nbe_ctx* c, const Tensor& src, int crop, const Tensor& cat) {
+    if (c->dry) return;
+    Planes s = src.p; s.G = c->mid / 4;
+    launch_crop(s, crop, cat.p, 0, c->vel, c->stream);
+}
+
+static int check_dims(int D, int H, int W) {
+    const int v[3] = {D, H, W};
+    for (int i = 0; i < 3; ++i)
+        if (v[i] < 104 || v[i] % 8 != 0)
+            return fail("input spatial size %d unsupported: each of (D,H,W) must be >= 104 and a multiple of 8 "
+                        "(all-VALID U-Net with three 2x levels, receptive-field crop 48)", v[i]);
+    return 0;
+}
+
+// the network body on a resident input tensor; returns conv_r01's output tensor (out_chan channels)
+static int network(nbe_ctx* c, const Tensor& tin, Tensor* yout) {
+    const int m = c->mid;
+    Tensor a, y0, y1, y2, t, cat0, cat1, cat2, r;
+    if (resblock(c, "conv_l00", tin, false, true, m, m, &a)) return 1;
+    if (resblock(c, "conv_l01", a, true, true, m, m, &y0)) return 1;
+    tfree(c, a);
+    cat0 = talloc(c, 2 * m, y0.p.D - 80, y0.p.H - 80, y0.p.W - 80);
+    if (cat0.off < 0) return fail("workspace exhausted (cat0)");
+    crop_into(c, y0, 40, cat0);
+    if (downblock(c, "down_l0", y0, &t)) return 1;
+    tfree(c, y0);
+
+    if (resblock(c, "conv_l1", t, true, true, m, m, &y1)) return 1;
+    tfree(c, t);
+    cat1 = talloc(c, 2 * m, y1.p.D - 32, y1.p.H - 32, y1.p.W - 32);
+    if (cat1.off < 0) return fail("workspace exhausted (cat1)");
+    crop_into(c, y1, 16, cat1);
+    if (downblock(c, "down_l1", y1, &t)) return 1;
+    tfree(c, y1);
+
+    if (resblock(c, "conv_l2", t, true, true, m, m, &y2)) return 1;
+    tfree(c, t);
+    cat2 = talloc(c, 2 * m, y2.p.D - 8, y2.p.H - 8, y2.p.W - 8);
+    if (cat2.off < 0) return fail("workspace exhausted (cat2)");
+    crop_into(c, y2, 4, cat2);
+    if (downblock(c, "down_l2", y2, &t)) return 1;
+    tfree(c, y2);
+
+    if (resblock(c, "conv_c", t, true, true, m, m, &r)) return 1;
+    tfree(c, t);
+
+    if (upblock(c, "up_r2", r, cat2)) return 1;
+    tfree(c, r);
+    if (resblock(c, "conv_r2", cat2, true, true, m, 2 * m, &r)) return 1;
+    tfree(c, cat2);
+
+    if (upblock(c, "up_r1", r, cat1)) return 1;
+    tfree(c, r);
+    if (resblock(c, "conv_r1", cat1, true, true, m, 2 * m, &r)) return 1;
+    tfree(c, cat1);
+
+    if (upblock(c, "up_r0", r, cat0)) return 1;
+    tfree(c, r);
+    if (resblock(c, "conv_r00", cat0, true, true, m, 2 * m, &r)) return 1;
+    tfree(c, cat0);
+
+    if (resblock(c, "conv_r01", r, true, false, c->out_chan, m, yout)) return 1;
+    tfree(c, r);
+    return 0;
+}
+
+// size the workspace for a (D,H,W) input with a dry run, then (re)allocate it
+static int ensure_workspace(nbe_ctx* c, int D, int H, int W) {
+    c->dry = true;
+    c->arena.reset();
+    Tensor tin = talloc(c, c->in_chan, D, H, W), y;
+    int rc = network(c, tin, &y);
+    c->dry = false;
+    if (rc) return rc;
+    const int64_t need = c->arena.high;
+    if (need > c->ws_bytes) {
+        if (c->ws) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+        HIPCHK(hipMalloc((void**)&c->ws, need));
+        // padded channel planes are read (against zero weights) but never written: they must hold finite values
+        HIPCHK(hipMemsetAsync(c->ws, 0, need, c->stream));
+        c->ws_bytes = need;
+    }
+    return 0;
+}
+
+static int require_ready(nbe_ctx* c) {
+    if (!c->have_weights) return fail("No parameters loaded. Call nbe_load_style_weights / nbe_load_premod_weights first.");
+    if (c->style && !c->modulated) return fail("style weights are loaded but nbe_set_cosmology(Om, Dz) has not been called");
+    return 0;
+}
+
+// one sub-box: `box` is a device-resident (C, Db, Hb, Wb) volume, the crop origin may be negative (periodic)
+static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0, int o1, int o2,
+                      int D, int H, int W, float Dz, float vel_fac, void* disp, void* velo, int out_dtype,
+                      int OD, int OH, int OW, int a0, int a1, int a2) {
+    c->arena.reset();
+    Tensor tin = talloc(c, c->in_chan, D, H, W), y;
+    // core :132-134: x = x * (Dz / 6)
+    launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f, c->stream);
+    if (network(c, tin, &y)) return 1;
+    launch_head(y.p, tin.p, 48, c->out_chan, Dz, vel_fac, c->vel, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, c->stream);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+static void free_layers(nbe_ctx* c) {
+    for (auto& kv : c->layers) {
+        Layer& L = kv.second;
+        (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
+        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias);
+    }
+    c->layers.clear();
+    c->have_weights = false; c->modulated = false;
+}
+
+static int kind_of(const nbe_layer_desc& d, int* kind) {
+    const std::string blk = d.block, lay = d.layer;
+    if (lay == "skip") { if (d.k != 1) return fail("%s/%s: skip layers have k=1", d.block, d.layer); *kind = 1; return 0; }
+    if (blk.rfind("down_", 0) == 0) { if (d.k != 2) return fail("%s: down layers have k=2", d.block); *kind = 2; return 0; }
+    if (blk.rfind("up_", 0) == 0) { if (d.k != 2) return fail("%s: up layers have k=2", d.block); *kind = 3; return 0; }
+    if (d.k != 3) return fail("%s/%s: conv layers have k=3", d.block, d.layer);
+    *kind = 0;
+    return 0;
+}
+
+static int expected_shape(nbe_ctx* c, const std::string& blk, const std::string& lay, int* cout, int* cin) {
+    const int m = c->mid;
+    int bi, bo;
+    if (blk == "conv_l00") { bi = c->in_chan; bo = m; }
+    else if (blk == "conv_r2" || blk == "conv_r1" || blk == "conv_r00") { bi = 2 * m; bo = m; }
+    else if (blk == "conv_r01") { bi = m; bo = c->out_chan; }
+    else { bi = m; bo = m; }
+    const int midc = bi > bo ? bi : bo;                     // style_blocks_vel.py:126
+    if (lay == "skip") { *cin = bi; *cout = bo; }
+    else if (blk.rfind("down_", 0) == 0 || blk.rfind("up_", 0) == 0) { *cin = bi; *cout = bo; }
+    else if (lay == "conv_0") { *cin = bi; *cout = midc; }
+    else if (lay == "conv_1") { *cin = midc; *cout = bo; }
+    else return fail("unknown layer %s/%s", blk.c_str(), lay.c_str());
+    return 0;
+}
+
+static const char* kBlocks[15] = {"conv_l00", "conv_l01", "down_l0", "conv_l1", "down_l1", "conv_l2", "down_l2", "conv_c",
+                                  "up_r2", "conv_r2", "up_r1", "conv_r1", "up_r0", "conv_r00", "conv_r01"};
+
+static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool style) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_layers(c);
+    for (int i = 0; i < n; ++i) {
+        const nbe_layer_desc& d = descs[i];
+        if (!d.block || !d.layer || !d.weight || !d.bias) return fail("layer %d: block, layer, weight and bias are required", i);
+        Layer L;
+        L.block = d.block; L.layer = d.layer; L.cout = d.cout; L.cin = d.cin; L.k = d.k;
+        if (kind_of(d, &L.kind)) return 1;
+        int ec, ei;
+        if (expected_shape(c, L.block, L.layer, &ec, &ei)) return 1;
+        if (ec != d.cout || ei != d.cin)
+            return fail("%s/%s: weight shape (%d,%d,k) does not match the architecture (%d,%d,k)", d.block, d.layer, d.cout, d.cin, ec, ei);
+        L.first = (L.block == "conv_l00") && (L.layer == "conv_0" || L.layer == "skip");     // nbody_emulator.py:243-246
+        const size_t nw = (size_t)d.cout * d.cin * d.k * d.k * d.k;
+        PackedW& pw = L.pw;
+        pw.mode = L.kind == 0 ? MODE_FLAT3 : (L.kind == 2 ? MODE_DOWN : MODE_FLAT1);
+        pw.ni = d.cout > 32 ? 2 : 1;
+        pw.cin = d.cin; pw.cout = d.cout;
+        pw.cin_pad = roundup(d.cin, mode_ck(pw.mode));
+        pw.ctiles = (d.cout + 32 * pw.ni - 1) / (32 * pw.ni);
+        pw.nsets = L.kind == 3 ? 8 : 1;
+        pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad;
+        HIPCHK(hipMalloc((void**)&pw.w, pw.floats * pw.nsets * 4));
+        if (c->vel) HIPCHK(hipMalloc((void**)&pw.dw, pw.floats * pw.nsets * 4));
+        const int nb = pw.ctiles * 32 * pw.ni;
+        HIPCHK(hipMalloc((void**)&pw.bias, nb * 4));
+        HIPCHK(hipMemset(pw.bias, 0, nb * 4));
+        HIPCHK(hipMemcpy(pw.bias, d.bias, d.cout * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&L.wn, nw * 4));
+        if (c->vel) HIPCHK(hipMalloc((void**)&L.dwn, nw * 4));
+        if (style) {
+            if (!d.style_weight || !d.style_bias) return fail("%s/%s: style_weight and style_bias are required", d.block, d.layer);
+            HIPCHK(hipMalloc((void**)&L.weight, nw * 4));
+            HIPCHK(hipMalloc((void**)&L.sw, d.cin * 2 * 4));
+            HIPCHK(hipMalloc((void**)&L.sb, d.cin * 4));
+            HIPCHK(hipMemcpy(L.weight, d.weight, nw * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(L.sw, d.style_weight, d.cin * 2 * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(L.sb, d.style_bias, d.cin * 4, hipMemcpyHostToDevice));
+        } else {
+            if (c->vel && !d.dweight) return fail("%s/%s: dweight is required for premodulated velocity weights", d.block, d.layer);
+            HIPCHK(hipMemcpy(L.wn, d.weight, nw * 4, hipMemcpyHostToDevice));
+            if (c->vel) HIPCHK(hipMemcpy(L.dwn, d.dweight, nw * 4, hipMemcpyHostToDevice));
+            launch_pack(L.wn, d.cout, d.cin, L.kind, pw, pw.w, c->stream);
+            if (c->vel) launch_pack(L.dwn, d.cout, d.cin, L.kind, pw, pw.dw, c->stream);
+        }
+        c->layers[L.block + "/" + L.layer] = L;
+    }
+    // completeness: 9 ResNet blocks x {skip, conv_0, conv_1} + 6 resample blocks x {conv_0} = 33 layers
+    for (const char* b : kBlocks) {
+        const bool rs = !strncmp(b, "down_", 5) || !strncmp(b, "up_", 3);
+        const char* need[3] = {"conv_0", rs ? nullptr : "skip", rs ? nullptr : "conv_1"};
+        for (const char* l : need)
+            if (l && !find_layer(c, b, l)) return fail("parameter tree is missing %s/%s", b, l);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_weights = true; c->style = style; c->modulated = !style;
+    c->mod_Om = NAN; c->mod_Dz = NAN;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* nbe_last_error(void) { return g_err.c_str(); }
+int nbe_version(void) { return 100; }
+
+int nbe_create(int device_id, nbe_ctx** out) {
+    if (!out) return fail("nbe_create: out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("nbe_create: no HIP device is visible; this library has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail("nbe_create: device %d out of range (0..%d)", device_id, ndev - 1);
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail("nbe_create: device %d is %s; the kernels are built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    nbe_ctx* c = new nbe_ctx();
+    c->device = device_id;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+int nbe_destroy(nbe_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    free_layers(c);
+    (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+int nbe_set_stream(nbe_ctx* c, void* s) {
+    if (!c) return fail("null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+int nbe_synchronize(nbe_ctx* c) {
+    if (!c) return fail("null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int nbe_set_arch(nbe_ctx* c, int in_chan, int out_chan, int mid_chan, float eps, int compute_vel) {
+    if (!c) return fail("null context");
+    if (in_chan < 1 || in_chan > 16) return fail("in_chan=%d unsupported (1..16)", in_chan);
+    if (out_chan < 1 || out_chan > 64) return fail("out_chan=%d unsupported (1..64)", out_chan);
+    if (out_chan != in_chan) return fail("out_chan (%d) must equal in_chan (%d): the head adds the cropped input (core :187)", out_chan, in_chan);
+    if (mid_chan < 8 || mid_chan % 8 != 0) return fail("mid_chan=%d unsupported (multiple of 8 required)", mid_chan);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_layers(c);
+    c->in_chan = in_chan; c->out_chan = out_chan; c->mid = mid_chan; c->eps = eps; c->vel = compute_vel != 0;
+    return 0;
+}
+
+int nbe_load_style_weights(nbe_ctx* c, const nbe_layer_desc* layers, int n) {
+    if (!c || !layers) return fail("null argument");
+    return load_weights(c, layers, n, true);
+}
+
+int nbe_load_premod_weights(nbe_ctx* c, const nbe_layer_desc* layers, int n) {
+    if (!c || !layers) return fail("null argument");
+    return load_weights(c, layers, n, false);
+}
+
+int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
+    if (!c) return fail("null context");
+    if (!c->have_weights) return fail("No parameters loaded. Call nbe_load_style_weights first.");
+    if (!c->style) return 0;
+    if (c->modulated && c->mod_Om == Om && c->mod_Dz == Dz) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    // s = ((Om - 0.3) * 5, Dz - 1) in float32 (core :126-128)
+    const float s0 = (Om - 0.3f) * 5.0f, s1 = Dz - 1.0f;
+    for (auto& kv : c->layers) {
+        Layer& L = kv.second;
+        launch_modulate(L.weight, L.sw, L.sb, L.cout, L.cin, L.k * L.k * L.k, s0, s1, c->eps, L.first ? 1 : 0,
+                        L.wn, c->vel ? L.dwn : nullptr, c->stream);
+        launch_pack(L.wn, L.cout, L.cin, L.kind, L.pw, L.pw.w, c->stream);
+        if (c->vel) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pw, L.pw.dw, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    c->modulated = true; c->mod_Om = Om; c->mod_Dz = Dz;
+    return 0;
+}
+
+int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float vel_fac, void* disp, void* vel) {
+    if (!c || !x || !disp) return fail("null argument");
+    if (require_ready(c)) return 1;
+    if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
+    if (check_dims(D, H, W)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    const int OD = D - 96, OH = H - 96, OW = W - 96;
+    const int64_t in_bytes = (int64_t)c->in_chan * D * H * W * 4, out_bytes = (int64_t)c->out_chan * OD * OH * OW * 4;
+    const bool xin_dev = is_device_ptr(x), out_dev = is_device_ptr(disp);
+    if (ensure_workspace(c, D, H, W)) return 1;
+    const float* xd = (const float*)x;
+    if (!xin_dev) {
+        if (in_bytes > c->box_in_bytes) { (void)hipFree(c->box_in); HIPCHK(hipMalloc((void**)&c->box_in, in_bytes)); c->box_in_bytes = in_bytes; }
+        HIPCHK(hipMemcpyAsync(c->box_in, x, in_bytes, hipMemcpyHostToDevice, c->stream));
+        xd = c->box_in;
+    }
+    char *dd = (char*)disp, *vd = (char*)vel;
+    if (!out_dev) {
+        const int64_t need = out_bytes * 2;
+        if (need > c->box_out_bytes) { (void)hipFree(c->box_out); HIPCHK(hipMalloc((void**)&c->box_out, need)); c->box_out_bytes = need; }
+        dd = c->box_out; vd = c->box_out + out_bytes;
+    }
+    if (run_subbox(c, xd, D, H, W, 0, 0, 0, D, H, W, Dz, vel_fac, dd, vd, NBE_F32, OD, OH, OW, 0, 0, 0)) return 1;
+    HIPCHK(hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(hipMemcpyAsync(disp, dd, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        if (c->vel) HIPCHK(hipMemcpyAsync(vel, vd, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!out_dev || !xin_dev) HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int nbe_process_box(nbe_ctx* c, const void* box, const int64_t size[3], const int ndiv[3], const int pad[6],
+                    float Dz, float vel_fac, void* disp, void* vel, int out_dtype, nbe_progress_cb cb, void* user) {
+    if (!c || !box || !disp || !size || !ndiv || !pad) return fail("null argument");
+    if (require_ready(c)) return 1;
+    if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
+    if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
+    for (int i = 0; i < 6; ++i)
+        if (pad[i] != 48) return fail("padding must be 48 on every side (receptive field of the network, subbox.py:43); got %d", pad[i]);
+    for (int i = 0; i < 3; ++i) {
+        if (ndiv[i] < 1 || size[i] < 1) return fail("size and ndiv must be positive");
+        if (size[i] > 2000000000LL / 4) return fail("box axis too large");
+    }
+    const int S0 = (int)size[0], S1 = (int)size[1], S2 = (int)size[2];
+    const int c0 = S0 / ndiv[0], c1 = S1 / ndiv[1], c2 = S2 / ndiv[2];                    // subbox.py:49 (floor)
+    const int D = c0 + 96, H = c1 + 96, W = c2 + 96;
+    if (check_dims(D, H, W)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t nvox = (int64_t)S0 * S1 * S2;
+    const int64_t in_bytes = nvox * c->in_chan * 4;
+    const int esz = out_dtype == NBE_F16 ? 2 : 4;
+    const int64_t out_bytes = nvox * c->out_chan * esz;
+    const bool in_dev = is_device_ptr(box), out_dev = is_device_ptr(disp);
+    if (ensure_workspace(c, D, H, W)) return 1;
+    const float* bd = (const float*)box;
+    if (!in_dev) {
+        if (in_bytes > c->box_in_bytes) { (void)hipFree(c->box_in); c->box_in = nullptr; c->box_in_bytes = 0;
+                                          HIPCHK(hipMalloc((void**)&c->box_in, in_bytes)); c->box_in_bytes = in_bytes; }
+        HIPCHK(hipMemcpyAsync(c->box_in, box, in_bytes, hipMemcpyHostToDevice, c->stream));
+        bd = c->box_in;
+    }
+    char *dd = (char*)disp, *vd = (char*)vel;
+    if (!out_dev) {
+        const int64_t need = out_bytes * (c->vel ? 2 : 1);
+        if (need > c->box_out_bytes) { (void)hipFree(c->box_out); c->box_out = nullptr; c->box_out_bytes = 0;
+                                       HIPCHK(hipMalloc((void**)&c->box_out, need)); c->box_out_bytes = need; }
+        dd = c->box_out; vd = c->box_out + out_bytes;
+    }
+    // subbox.py:168-170: outputs start as zeros (voxels beyond ndiv*crop_size stay zero)
+    if ((int64_t)c0 * ndiv[0] != S0 || (int64_t)c1 * ndiv[1] != S1 || (int64_t)c2 * ndiv[2] != S2 || !out_dev) {
+        HIPCHK(hipMemsetAsync(dd, 0, out_bytes, c->stream));
+        if (c->vel) HIPCHK(hipMemsetAsync(vd, 0, out_bytes, c->stream));
+    }
+    const int total = ndiv[0] * ndiv[1] * ndiv[2];
+    for (int idx = 0; idx < total; ++idx) {
+        // subbox.py:60-66: row-major over ndiv, last axis fastest
+        const int a0 = (idx / (ndiv[1] * ndiv[2])) * c0, a1 = ((idx / ndiv[2]) % ndiv[1]) * c1, a2 = (idx % ndiv[2]) * c2;
+        if (run_subbox(c, bd, S0, S1, S2, a0 - 48, a1 - 48, a2 - 48, D, H, W, Dz, vel_fac, dd, vd, out_dtype,
+                       S0, S1, S2, a0, a1, a2)) return 1;
+        if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb(idx + 1, total, user); }
+    }
+    HIPCHK(hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(hipMemcpyAsync(disp, dd, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        if (c->vel) HIPCHK(hipMemcpyAsync(vel, vd, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!out_dev || !in_dev) HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- test hooks -----------------------------------------------------------------------------------
+
+int nbe_test_modulate(nbe_ctx* c, const float* weight, const float* sw, const float* sb, int cout, int cin, int k,
+                      float s0, float s1, float eps, int first_layer, float* w_n, float* dw_tot) {
+    if (!c) return fail("null context");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nw = (size_t)cout * cin * k * k * k;
+    float *dw_ = nullptr, *dsw = nullptr, *dsb = nullptr, *dwn = nullptr, *ddw = nullptr;
+    HIPCHK(hipMalloc((void**)&dw_, nw * 4)); HIPCHK(hipMalloc((void**)&dsw, cin * 8)); HIPCHK(hipMalloc((void**)&dsb, cin * 4));
+    HIPCHK(hipMalloc((void**)&dwn, nw * 4)); HIPCHK(hipMalloc((void**)&ddw, nw * 4));
+    HIPCHK(hipMemcpy(dw_, weight, nw * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsw, sw, cin * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsb, sb, cin * 4, hipMemcpyHostToDevice));
+    launch_modulate(dw_, dsw, dsb, cout, cin, k * k * k, s0, s1, eps, first_layer, dwn, dw_tot ? ddw : nullptr, c->stream);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(w_n, dwn, nw * 4, hipMemcpyDeviceToHost));
+    if (dw_tot) HIPCHK(hipMemcpy(dw_tot, ddw, nw * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dw_); (void)hipFree(dsw); (void)hipFree(dsb); (void)hipFree(dwn); (void)hipFree(ddw);
+    return 0;
+}
+
+int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
+                   const float* w, const float* dw, const float* bias, int cout, const float* res, const float* dres,
+                   float* y, float* dy) {
+    if (!c || !x || !w || !bias || !y) return fail("null argument");
+    if (kind < 0 || kind > 3) return fail("kind must be 0..3");
+    HIPCHK(hipSetDevice(c->device));
+    const bool vel = dw != nullptr && dy != nullptr, has_dx = vel && dx != nullptr;
+    const bool saved_vel = c->vel;
+    c->vel = vel;
+    const int k = kind == 0 ? 3 : kind == 1 ? 1 : 2;
+    int OD, OH, OW;
+    if (kind == 0) { OD = D - 2; OH = H - 2; OW = W - 2; }
+    else if (kind == 1) { OD = D - 2 * crop; OH = H - 2 * crop; OW = W - 2 * crop; }
+    else if (kind == 2) { OD = D / 2; OH = H / 2; OW = W / 2; }
+    else { OD = 2 * D; OH = 2 * H; OW = 2 * W; }
+    const size_t nin = (size_t)cin * D * H * W, nout = (size_t)cout * OD * OH * OW, nw = (size_t)cout * cin * k * k * k;
+    int rc = 0;
+    float *dxin = nullptr, *ddx = nullptr, *dwt = nullptr, *ddw = nullptr, *dout = nullptr;
+    Layer L;
+    char* ws = nullptr;
+    do {
+        L.cout = cout; L.cin = cin; L.k = k; L.kind = kind;
+        PackedW& pw = L.pw;
+        pw.mode = kind == 0 ? MODE_FLAT3 : (kind == 2 ? MODE_DOWN : MODE_FLAT1);
+        pw.ni = cout > 32 ? 2 : 1; pw.cin = cin; pw.cout = cout;
+        pw.cin_pad = roundup(cin, mode_ck(pw.mode));
+        pw.ctiles = (cout + 32 * pw.ni - 1) / (32 * pw.ni);
+        pw.nsets = kind == 3 ? 8 : 1;
+        pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad;
+#define TCHK(e) if ((e) != hipSuccess) { rc = fail("hip error in nbe_test_layer: %s", hipGetErrorString(hipGetLastError())); break; }
+        TCHK(hipMalloc((void**)&pw.w, pw.floats * pw.nsets * 4));
+        if (vel) TCHK(hipMalloc((void**)&pw.dw, pw.floats * pw.nsets * 4));
+        const int nb = pw.ctiles * 32 * pw.ni;
+        TCHK(hipMalloc((void**)&pw.bias, nb * 4)); TCHK(hipMemset(pw.bias, 0, nb * 4));
+        TCHK(hipMemcpy(pw.bias, bias, cout * 4, hipMemcpyHostToDevice));
+        TCHK(hipMalloc((void**)&dwt, nw * 4)); TCHK(hipMemcpy(dwt, w, nw * 4, hipMemcpyHostToDevice));
+        launch_pack(dwt, cout, cin, kind, pw, pw.w, c->stream);
+        if (vel) { TCHK(hipMalloc((void**)&ddw, nw * 4)); TCHK(hipMemcpy(ddw, dw, nw * 4, hipMemcpyHostToDevice));
+                   launch_pack(ddw, cout, cin, kind, pw, pw.dw, c->stream); }
+        TCHK(hipMalloc((void**)&dxin, nin * 4)); TCHK(hipMemcpy(dxin, x, nin * 4, hipMemcpyHostToDevice));
+        if (has_dx) { TCHK(hipMalloc((void**)&ddx, nin * 4)); TCHK(hipMemcpy(ddx, dx, nin * 4, hipMemcpyHostToDevice)); }
+        TCHK(hipMalloc((void**)&dout, nout * 4));
+        // private workspace: input, output, residual planes
+        auto mk = [&](int C, int d, int h, int wd, int64_t* bytes) {
+            Planes p; p.G = planes_for(C); p.D = d; p.H = h; p.W = wd; p.pstride = (p.vox() + 63) & ~int64_t(63);
+            *bytes = (int64_t)p.G * p.pstride * 16; return p; };
+        int64_t bi, bo;
+        Planes pin = mk(cin, D, H, W, &bi), pout = mk(cout, OD, OH, OW, &bo), pres = pout;
+        const int64_t tot = 2 * bi + 4 * bo;
+        TCHK(hipMalloc((void**)&ws, tot)); TCHK(hipMemsetAsync(ws, 0, tot, c->stream));
+        pin.x = (float*)ws; pin.dx = (float*)(ws + bi);
+        pout.x = (float*)(ws + 2 * bi); pout.dx = (float*)(ws + 2 * bi + bo);
+        pres.x = (float*)(ws + 2 * bi + 2 * bo); pres.dx = (float*)(ws + 2 * bi + 3 * bo);
+        launch_to_planes(dxin, cin, pin, false, 1.0f, c->stream);
+        if (has_dx) launch_to_planes(ddx, cin, pin, true, 1.0f, c->stream);
+        if (flags & F_RES) {
+            if (!res) { rc = fail("residual flag set but res is NULL"); break; }
+            TCHK(hipMemcpyAsync(dout, res, nout * 4, hipMemcpyHostToDevice, c->stream));
+            launch_to_planes(dout, cout, pres, false, 1.0f, c->stream);
+            if (vel && dres) { TCHK(hipStreamSynchronize(c->stream)); TCHK(hipMemcpyAsync(dout, dres, nout * 4, hipMemcpyHostToDevice, c->stream));
+                               launch_to_planes(dout, cout, pres, true, 1.0f, c->stream); }
+            TCHK(hipStreamSynchronize(c->stream));
+        }
+        ConvLaunch cl; cl.in = pin; cl.out = pout; cl.res = pres; cl.flags = flags;
+        if (kind == 0) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; run_conv(c, L, cl, has_dx); }
+        else if (kind == 1) { cl.in_off = ((int64_t)crop * H + crop) * W + crop; cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; run_conv(c, L, cl, has_dx); }
+        else if (kind == 2) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; run_conv(c, L, cl, has_dx); }
+        else {
+            for (int p = 0; p < 8; ++p) {
+                ConvLaunch u = cl; u.Dv = D; u.Hv = H; u.Wv = W; u.osz = 2; u.oz = (p >> 2) & 1; u.oy = (p >> 1) & 1; u.ox = p & 1; u.set = p;
+                run_conv(c, L, u, has_dx);
+            }
+        }
+        launch_from_planes(pout, false, cout, dout, c->stream);
+        TCHK(hipStreamSynchronize(c->stream));
+        TCHK(hipMemcpy(y, dout, nout * 4, hipMemcpyDeviceToHost));
+        if (vel) {
+            launch_from_planes(pout, true, cout, dout, c->stream);
+            TCHK(hipStreamSynchronize(c->stream));
+            TCHK(hipMemcpy(dy, dout, nout * 4, hipMemcpyDeviceToHost));
+        }
+        TCHK(hipGetLastError());
+#undef TCHK
+    } while (0);
+    c->vel = saved_vel;
+    (void)hipFree(dxin); (void)hipFree(ddx); (void)hipFree(dwt); (void)hipFree(ddw); (void)hipFree(dout); (void)hipFree(ws);
+    (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias);
+    return rc;
+}
+
+int nbe_profile_enable(nbe_ctx* c, int on) { if (!c) return fail("null context"); prof_collect(c); c->prof = on != 0; return 0; }
+int nbe_profile_reset(nbe_ctx* c) { if (!c) return fail("null context"); prof_collect(c); c->prof_entries.clear(); return 0; }
+int nbe_profile_count(nbe_ctx* c) { if (!c) return 0; prof_collect(c); return (int)c->prof_entries.size(); }
+int nbe_profile_entry(nbe_ctx* c, int i, char* name, int cap, double* ms, int64_t* launches, double* flops) {
+    if (!c || i < 0 || i >= (int)c->prof_entries.size()) return fail("profile entry out of range");
+    const ProfEntry& e = c->prof_entries[i];
+    if (name && cap > 0) { strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (ms) *ms = e.ms; if (launches) *launches = e.launches; if (flops) *flops = e.flops;
+    return 0;
+}
+int64_t nbe_workspace_bytes(nbe_ctx* c) { return c ? c->ws_bytes : 0; }
+
+}  // extern "C"

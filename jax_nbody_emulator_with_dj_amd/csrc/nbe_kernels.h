@@ -1,0 +1,80 @@
+// Host-visible launch interface of the gfx950 kernels (nbe_kernels.hip).
+// Internal to the library: the public C-ABI is include/nbe.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nbe {
+
+// Activation storage ("C/4-blocked"): a tensor of C channels over V = D*H*W
+// voxels is C/4 planes; plane g holds float4 {c=4g..4g+3} per voxel, voxels in
+// row-major (z,y,x) order.  `pstride` is the distance between planes in voxels.
+struct Planes {
+    float* x = nullptr;      // primal
+    float* dx = nullptr;     // tangent (d/dDz); nullptr in displacement-only mode
+    int64_t pstride = 0;     // voxels between consecutive planes
+    int G = 0;               // number of planes (= padded channels / 4)
+    int D = 0, H = 0, W = 0; // geometry
+    int64_t vox() const { return (int64_t)D * H * W; }
+};
+
+enum ConvMode { MODE_FLAT3 = 0, MODE_FLAT1 = 1, MODE_DOWN = 2 };
+enum ConvFlags { F_ACT = 1, F_RES = 2 };
+
+// Tile constants shared by the weight packer and the conv kernel.
+constexpr int TILE_VOX = 256;                 // voxels per workgroup tile
+inline constexpr int mode_taps(int mode) { return mode == MODE_FLAT3 ? 3 : 1; }
+inline constexpr int mode_nseg(int mode) { return mode == MODE_FLAT3 ? 9 : (mode == MODE_DOWN ? 8 : 1); }
+inline constexpr int mode_ck(int mode) { return mode == MODE_FLAT3 ? 8 : 16; }
+
+// One packed weight set (see pack_index in nbe_kernels.hip for the layout).
+struct PackedW {
+    float* w = nullptr;      // [ct][stage][tap][CK/4][COUT_T][4]
+    float* dw = nullptr;
+    float* bias = nullptr;   // padded to ct*COUT_T
+    int mode = 0, ni = 2;    // COUT_T = 32*ni
+    int cin = 0, cout = 0;   // logical channels
+    int cin_pad = 0;         // multiple of CK
+    int ctiles = 0;          // cout tiles
+    int64_t floats = 0;      // size of w (and dw) in floats, per parity set
+    int nsets = 1;           // 8 for the up-sample layer (one set per output parity)
+};
+
+struct ConvLaunch {
+    Planes in;               // input planes (G*4 >= cin_pad)
+    int64_t in_off = 0;      // FLAT modes: flat input offset of output position q (crop)
+    int Dv = 0, Hv = 0, Wv = 0;   // FLAT: valid output extents along z,y,x in q coordinates; DOWN: output dims
+    Planes out;              // output planes; written planes are out_g0 + cout group
+    int out_g0 = 0;
+    int osz = 1, oz = 0, oy = 0, ox = 0;   // output voxel = (z*osz+oz, y*osz+oy, x*osz+ox) in out geometry
+    Planes res;              // residual (same geometry as out), used when flags & F_RES
+    int flags = 0;
+    int set = 0;             // weight set (parity) index
+};
+
+void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, hipStream_t s);
+
+// weight preparation -------------------------------------------------------
+// (w_n, dw_tot) in OIDHW from raw style parameters (style_layers_vel.py:62-105)
+void launch_modulate(const float* weight, const float* style_weight, const float* style_bias,
+                     int cout, int cin, int k3, float s0, float s1, float eps, int first_layer,
+                     float* w_n, float* dw_tot /*nullable*/, hipStream_t s);
+// OIDHW -> packed layout; `kind`: 0 conv3, 1 skip(1x1x1), 2 down(k2 s2), 3 up(k2, 8 parity sets)
+void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s);
+
+// data movement --------------------------------------------------------------
+// periodic crop of a (C, Db, Hb, Wb) float box into input planes, scaled by `scale`
+void launch_gather(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                   const Planes& dst, float scale, hipStream_t s);
+// NCDHW (C,D,H,W) dense -> planes (+scale), and back (debug / apply path)
+void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, hipStream_t s);
+void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, hipStream_t s);
+// centre crop by c voxels per side into planes [g0, g0+src.G) of dst
+void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s);
+// head: disp = (y + x0)*6 ; vel = dy*(vf*6) + x0*(vf*6/Dz); x0 = input planes cropped by `c0`;
+// written to a (C, Db, Hb, Wb) box at origin (a0,a1,a2); out_dtype 0 = f32, 1 = f16
+void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+                 void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                 hipStream_t s);
+
+}  // namespace nbe

@@ -1,0 +1,508 @@
+// gfx950 (MI355X, CDNA4) kernels of the N-body emulator forward.
+//
+// What they replace in the reference (all of it XLA-generated code there):
+//   conv_mfma_kernel   jax.lax.conv_general_dilated call sites
+//                      style_layers_vel.py:109-141 (k=3, k=1, k=2 s=2) and :236-269 (lhs_dilation
+//                      up-sample), plus the bias add, LeakyReLUVel (layers_vel.py:182-186), the ResNet
+//                      residual add (style_blocks_vel.py:158-164) as epilogues
+//   modulate_kernel    weight modulation / demodulation / d/dDz (style_layers_vel.py:62-105,
+//                      nbody_emulator.py:189-219)
+//   gather/head        subbox.py:197-215 crop + paste, core :132-139 (input scale, x0) and :187-193
+//
+// Design: activations are stored as C/4 planes of float4 per voxel.  A 3x3x3 VALID
+// convolution over a dense (D,H,W) volume is a sum of 27 "flat shifts": output flat position q reads
+// input flat positions q + dz*H*W + dy*W + dx.  The kernel sweeps 256 consecutive flat positions per
+// workgroup (positions whose x/y run past the valid extent are computed and discarded, ~2/W+2/H waste),
+// stages one (dz,dy) row segment of 8 channels at a time into LDS with direct global->LDS DMA, serves the
+// three dx taps from the same segment by shifting the LDS read address, and contracts with fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: A = weights [cout x k], B = activations [k x voxel]) so that each lane ends up
+// with 4 consecutive output channels of one voxel = one float4 store into the output plane.
+// The tangent (velocity) path shares every staged operand: y += W.X, dy += dW.X + W.dX.
+
+#include "nbe_kernels.h"
+
+namespace nbe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
+extern __shared__ __attribute__((aligned(16))) f32x4 lds_dyn[];
+
+struct ConvKArgs {
+    const float* x; const float* dx; long in_pstride;
+    int D, H, W; long P; long in_off;
+    int Dv, Hv, Wv; long Q;
+    float* y; float* dy; long out_pstride; int out_g0;
+    int Ho, Wo; int osz, oz, oy, ox;
+    const float* r; const float* dr; long res_pstride;
+    const float* bias; const float* w; const float* dw;
+    int nchunk; int cout_groups; int flags; int ntiles;
+};
+
+__device__ __forceinline__ void dma16(const float* src, f32x4* dst_wave_base) {
+    // 64 lanes x 16 B: LDS destination = wave-uniform base + lane*16 (hardware rule), source per lane.
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)src, (LDS_AS void*)dst_wave_base, 16, 0, 0);
+}
+
+template <int MODE, bool VEL, bool HAS_DX, int NI>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
+    constexpr int CK = mode_ck(MODE), GL = CK / 4, TAPS = mode_taps(MODE);
+    constexpr int COUT_T = 32 * NI;
+    constexpr int XV = (MODE == MODE_FLAT3) ? 320 : 256;
+    constexpr int WP = TAPS * GL * COUT_T;           // 16-byte pieces of one weight stage
+    constexpr int XP = GL * XV;                      // 16-byte pieces of one activation stage
+    constexpr bool DX = VEL && HAS_DX;
+    constexpr int OFF_W = 0, OFF_DW = WP, OFF_X = OFF_DW + (VEL ? WP : 0), OFF_DXX = OFF_X + XP;
+    constexpr int BUF = OFF_DXX + (DX ? XP : 0);
+    constexpr int NIW = WP / 64, NIX = XP / 64;
+    constexpr int NW_TOT = NIW * (VEL ? 2 : 1);
+    constexpr int NINSTR = NW_TOT + NIX * (DX ? 2 : 1);
+    static_assert(WP % 64 == 0 && XP % 64 == 0, "stage arrays must be whole wave-instructions");
+
+    f32x4* lds = lds_dyn;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run
+    // of tiles so that neighbouring tiles (which share input rows) hit the same L2.  Bijective form.
+    int tile;
+    {
+        const int nt = a.ntiles, b = blockIdx.x;
+        const int qd = nt >> 3, rm = nt & 7, xcd = b & 7;
+        tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
+    }
+    const int ct = blockIdx.y;
+    const long q0 = (long)tile * TILE_VOX;
+    const int nchunk = a.nchunk;
+    const int nstage = mode_nseg(MODE) * nchunk;
+    const long HW = (long)a.H * a.W;
+
+    int* inbase = (int*)(lds + 2 * BUF);             // DOWN mode: input voxel of each tile slot
+    if (MODE == MODE_DOWN) {
+        long o = q0 + tid;
+        if (o > a.Q - 1) o = a.Q - 1;
+        const int hw = a.Hv * a.Wv;
+        const int zo = (int)(o / hw), rem = (int)(o - (long)zo * hw);
+        const int yo = rem / a.Wv, xo = rem - yo * a.Wv;
+        inbase[tid] = (int)((2L * zo * a.H + 2 * yo) * a.W + 2 * xo);
+        __syncthreads();
+    }
+
+    auto issue = [&](int s, int b) {
+        const int seg = s / nchunk, chunk = s - seg * nchunk;
+        long segoff;
+        if (MODE == MODE_FLAT3) segoff = (seg / 3) * HW + (seg % 3) * a.W;
+        else if (MODE == MODE_DOWN) segoff = (seg >> 2) * HW + ((seg >> 1) & 1) * a.W + (seg & 1);
+        else segoff = 0;
+        const long wbase = ((long)(ct * nstage + s) * WP) * 4;
+        f32x4* buf = lds + b * BUF;
+#pragma unroll
+        for (int t = 0; t < (NINSTR + 3) / 4; ++t) {
+            const int n = wave + 4 * t;              // wave-uniform instruction slot
+            if (n < NIW) {
+                dma16(a.w + wbase + (long)(n * 64 + lane) * 4, buf + OFF_W + n * 64);
+            } else if (VEL && n < NW_TOT) {
+                const int m = n - NIW;
+                dma16(a.dw + wbase + (long)(m * 64 + lane) * 4, buf + OFF_DW + m * 64);
+            } else if (n < NINSTR) {
+                const bool tang = DX && n >= NW_TOT + NIX;
+                const int m = n - NW_TOT - (tang ? NIX : 0);
+                const int gl = (m * 64) / XV;
+                const int vl = (m * 64) % XV + lane;
+                long v;
+                if (MODE == MODE_DOWN) v = (long)inbase[vl] + segoff;
+                else {
+                    v = q0 + a.in_off + segoff + vl;
+                    if (v > a.P - 1) v = a.P - 1;
+                }
+                const long off = ((long)(chunk * GL + gl) * a.in_pstride + v) * 4;
+                dma16((tang ? a.dx : a.x) + off, buf + (tang ? OFF_DXX : OFF_X) + m * 64);
+            }
+        }
+    };
+
+    f32x16 accy[NI][2];
+    f32x16 accd[NI][2];
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accy[it][jt][e] = 0.f; accd[it][jt][e] = 0.f; }
+
+    auto compute = [&](int b) {
+        const f32x4* buf = lds + b * BUF;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+            for (int kg = 0; kg < CK / 8; ++kg) {
+                f32x4 wv[NI], dwv[NI], xv[2], dxv[2];
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int o = (tap * GL + 2 * kg + lh) * COUT_T + 32 * it + li;
+                    wv[it] = buf[OFF_W + o];
+                    if (VEL) dwv[it] = buf[OFF_DW + o];
+                }
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const int o = (2 * kg + lh) * XV + wave * 64 + 32 * jt + li + (MODE == MODE_FLAT3 ? tap : 0);
+                    xv[jt] = buf[OFF_X + o];
+                    if (DX) dxv[jt] = buf[OFF_DXX + o];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int it = 0; it < NI; ++it) {
+#pragma unroll
+                        for (int jt = 0; jt < 2; ++jt) {
+                            accy[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[it][r], xv[jt][r], accy[it][jt], 0, 0, 0);
+                            if (VEL) accd[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dwv[it][r], xv[jt][r], accd[it][jt], 0, 0, 0);
+                            if (DX) accd[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[it][r], dxv[jt][r], accd[it][jt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    issue(0, 0);
+    __syncthreads();                                  // hipcc drains the DMA (vmcnt(0)) at the barrier
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) issue(s + 1, (s + 1) & 1);
+        compute(s & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual, LeakyReLU (+tangent), float4 stores ----------------------------
+    const bool act = a.flags & F_ACT, res = a.flags & F_RES;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const long q = q0 + wave * 64 + 32 * jt + li;
+        bool valid = q < a.Q;
+        long o;
+        if (MODE == MODE_DOWN) {
+            o = q;
+        } else {
+            const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
+            const int yy = rem / a.W, xx = rem - yy * a.W;
+            valid = valid && xx < a.Wv && yy < a.Hv && z < a.Dv;
+            o = ((long)(z * a.osz + a.oz) * a.Ho + (yy * a.osz + a.oy)) * a.Wo + (xx * a.osz + a.ox);
+        }
+        if (!valid) continue;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cgl = 8 * it + 2 * k + lh;                  // cout group inside the tile
+                const int cg = ct * (COUT_T / 4) + cgl;
+                if (cg >= a.cout_groups) continue;
+                const f32x4 bv = *(const f32x4*)(a.bias + cg * 4);
+                f32x4 v, dv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = accy[it][jt][4 * k + e] + bv[e]; dv[e] = accd[it][jt][4 * k + e]; }
+                if (res) {
+                    const long ro = ((long)cg * a.res_pstride + o) * 4;
+                    const f32x4 rv = *(const f32x4*)(a.r + ro);
+                    v += rv;
+                    if (VEL) { const f32x4 drv = *(const f32x4*)(a.dr + ro); dv += drv; }
+                }
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (VEL) dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                        v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                    }
+                }
+                const long oo = ((long)(a.out_g0 + cg) * a.out_pstride + o) * 4;
+                *(f32x4*)(a.y + oo) = v;
+                if (VEL) *(f32x4*)(a.dy + oo) = dv;
+            }
+        }
+    }
+}
+
+template <int MODE, bool VEL, bool HAS_DX, int NI>
+static void launch_conv_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
+    constexpr int CK = mode_ck(MODE), GL = CK / 4, TAPS = mode_taps(MODE);
+    constexpr int XV = (MODE == MODE_FLAT3) ? 320 : 256;
+    constexpr int WP = TAPS * GL * 32 * NI, XP = GL * XV;
+    constexpr int BUF = WP * (VEL ? 2 : 1) + XP * ((VEL && HAS_DX) ? 2 : 1);
+    constexpr size_t smem = (size_t)2 * BUF * 16 + 256 * sizeof(int);
+    auto kern = conv_mfma_kernel<MODE, VEL, HAS_DX, NI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    dim3 grid(ka.ntiles, ctiles, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
+}
+
+void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, hipStream_t s) {
+    ConvKArgs ka;
+    ka.x = L.in.x; ka.dx = L.in.dx; ka.in_pstride = L.in.pstride;
+    ka.D = L.in.D; ka.H = L.in.H; ka.W = L.in.W; ka.P = L.in.vox(); ka.in_off = L.in_off;
+    ka.Dv = L.Dv; ka.Hv = L.Hv; ka.Wv = L.Wv;
+    if (pw.mode == MODE_DOWN) ka.Q = (long)L.Dv * L.Hv * L.Wv;
+    else ka.Q = ((long)(L.Dv - 1) * L.in.H + (L.Hv - 1)) * L.in.W + L.Wv;
+    ka.y = L.out.x; ka.dy = L.out.dx; ka.out_pstride = L.out.pstride; ka.out_g0 = L.out_g0;
+    ka.Ho = L.out.H; ka.Wo = L.out.W; ka.osz = L.osz; ka.oz = L.oz; ka.oy = L.oy; ka.ox = L.ox;
+    ka.r = L.res.x; ka.dr = L.res.dx; ka.res_pstride = L.res.pstride;
+    ka.bias = pw.bias;
+    ka.w = pw.w + (size_t)L.set * pw.floats;
+    ka.dw = pw.dw ? pw.dw + (size_t)L.set * pw.floats : nullptr;
+    ka.nchunk = pw.cin_pad / mode_ck(pw.mode);
+    ka.cout_groups = (pw.cout + 3) / 4;
+    ka.flags = L.flags;
+    ka.ntiles = (int)((ka.Q + TILE_VOX - 1) / TILE_VOX);
+    const int ct = pw.ctiles;
+#define NBE_DISPATCH(MODE)                                                                   \
+    if (vel) {                                                                               \
+        if (has_dx) { if (pw.ni == 2) launch_conv_t<MODE, true, true, 2>(ka, ct, s);        \
+                      else launch_conv_t<MODE, true, true, 1>(ka, ct, s); }                 \
+        else        { if (pw.ni == 2) launch_conv_t<MODE, true, false, 2>(ka, ct, s);       \
+                      else launch_conv_t<MODE, true, false, 1>(ka, ct, s); }                \
+    } else {                                                                                 \
+        if (pw.ni == 2) launch_conv_t<MODE, false, false, 2>(ka, ct, s);                     \
+        else launch_conv_t<MODE, false, false, 1>(ka, ct, s);                                \
+    }
+    if (pw.mode == MODE_FLAT3) { NBE_DISPATCH(MODE_FLAT3) }
+    else if (pw.mode == MODE_FLAT1) { NBE_DISPATCH(MODE_FLAT1) }
+    else { NBE_DISPATCH(MODE_DOWN) }
+#undef NBE_DISPATCH
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight preparation
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += scratch[i];
+    return t;
+}
+
+// one workgroup per output filter: reduction over Cin*k^3 with wavefront shuffles
+__global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__ weight,
+                                                       const float* __restrict__ sw,
+                                                       const float* __restrict__ sb,
+                                                       int cin, int k3, float s0, float s1, float eps,
+                                                       int first_layer, float* __restrict__ w_n,
+                                                       float* __restrict__ dw_tot) {
+    __shared__ double scratch[4];
+    const int co = blockIdx.x;
+    const int n = cin * k3;
+    const float* wr = weight + (size_t)co * n;
+    double sww = 0.0, swd = 0.0;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int ci = e / k3;
+        const float smod = sw[2 * ci] * s0 + sw[2 * ci + 1] * s1 + sb[ci];
+        const float w = wr[e] * smod;
+        const float dws = wr[e] * sw[2 * ci + 1];
+        sww += (double)w * w;
+        swd += (double)w * dws;
+    }
+    sww = block_sum(sww, scratch);
+    swd = block_sum(swd, scratch);
+    const float norm = sqrtf((float)sww + eps);
+    const float dnorm = -(float)swd / (norm * norm * norm);
+    const float inv_dz = 1.0f / (s1 + 1.0f);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int ci = e / k3;
+        const float smod = sw[2 * ci] * s0 + sw[2 * ci + 1] * s1 + sb[ci];
+        const float w = wr[e] * smod;
+        const float dws = wr[e] * sw[2 * ci + 1];
+        const float wn = w / norm;
+        w_n[(size_t)co * n + e] = wn;
+        if (dw_tot) {
+            float d = dws / norm + w * dnorm;
+            if (first_layer) d += wn * inv_dz;
+            dw_tot[(size_t)co * n + e] = d;
+        }
+    }
+}
+
+void launch_modulate(const float* weight, const float* style_weight, const float* style_bias,
+                     int cout, int cin, int k3, float s0, float s1, float eps, int first_layer,
+                     float* w_n, float* dw_tot, hipStream_t s) {
+    hipLaunchKernelGGL(modulate_kernel, dim3(cout), dim3(256), 0, s, weight, style_weight, style_bias,
+                       cin, k3, s0, s1, eps, first_layer, w_n, dw_tot);
+}
+
+// packed layout: [set][ct][stage = seg*nchunk + chunk][tap][gl][co][e]; channel = chunk*CK + gl*4 + e
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int cout, int cin, int kind,
+                                                   int mode, int ni, int nchunk, long floats_per_set,
+                                                   int nsets, float* __restrict__ dst) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= floats_per_set * nsets) return;
+    const int CK = mode_ck(mode), GL = CK / 4, TAPS = mode_taps(mode), COUT_T = 32 * ni;
+    const int nstage = mode_nseg(mode) * nchunk;
+    long r = idx;
+    const int e = (int)(r % 4); r /= 4;
+    const int co = (int)(r % COUT_T); r /= COUT_T;
+    const int gl = (int)(r % GL); r /= GL;
+    const int tap = (int)(r % TAPS); r /= TAPS;
+    const int stage = (int)(r % nstage); r /= nstage;
+    const long per_set_ct = floats_per_set / ((long)nstage * TAPS * GL * COUT_T * 4);
+    const int ct = (int)(r % per_set_ct); r /= per_set_ct;
+    const int set = (int)r;
+    const int seg = stage / nchunk, chunk = stage - seg * nchunk;
+    const int ci = chunk * CK + gl * 4 + e;
+    const int oc = ct * COUT_T + co;
+    int k, kz, ky, kx;
+    if (kind == 0) { k = 3; kz = seg / 3; ky = seg % 3; kx = tap; }
+    else if (kind == 1) { k = 1; kz = ky = kx = 0; }
+    else if (kind == 2) { k = 2; kz = seg >> 2; ky = (seg >> 1) & 1; kx = seg & 1; }
+    else { k = 2; kz = 1 - ((set >> 2) & 1); ky = 1 - ((set >> 1) & 1); kx = 1 - (set & 1); }
+    float v = 0.f;
+    if (oc < cout && ci < cin) v = w[(((size_t)oc * cin + ci) * k + kz) * k * k + ky * k + kx];
+    dst[idx] = v;
+}
+
+void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s) {
+    const long total = pw.floats * pw.nsets;
+    const int nchunk = pw.cin_pad / mode_ck(pw.mode);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
+                       kind, pw.mode, pw.ni, nchunk, pw.floats, pw.nsets, dst);
+}
+
+// ------------------------------------------------------------------------------------------------
+// data movement
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ box, int C, int Db, int Hb, int Wb,
+                                                     int a0, int a1, int a2, float* __restrict__ dst,
+                                                     long pstride, int G, int D, int H, int W, float scale) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long V = (long)D * H * W;
+    if (v >= V) return;
+    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const int bz = ((a0 + z) % Db + Db) % Db, by = ((a1 + y) % Hb + Hb) % Hb, bx = ((a2 + x) % Wb + Wb) % Wb;
+    const long bo = ((long)bz * Hb + by) * Wb + bx;
+    const long bstride = (long)Db * Hb * Wb;
+    for (int g = 0; g < G; ++g) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * g + e;
+            o[e] = c < C ? box[c * bstride + bo] * scale : 0.f;
+        }
+        *(f32x4*)(dst + ((long)g * pstride + v) * 4) = o;
+    }
+}
+
+void launch_gather(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                   const Planes& dst, float scale, hipStream_t s) {
+    const long V = dst.vox();
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, box, C, Db, Hb, Wb,
+                       a0, a1, a2, dst.x, dst.pstride, dst.G, dst.D, dst.H, dst.W, scale);
+}
+
+void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, hipStream_t s) {
+    // a dense (C,D,H,W) array is a "box" of the same size gathered at origin 0
+    const long V = dst.vox();
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, src, C, dst.D, dst.H,
+                       dst.W, 0, 0, 0, tangent ? dst.dx : dst.x, dst.pstride, dst.G, dst.D, dst.H, dst.W, scale);
+}
+
+__global__ __launch_bounds__(256) void from_planes_kernel(const float* __restrict__ src, long pstride, long V, int C,
+                                                          float* __restrict__ dst) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    for (int g = 0; 4 * g < C; ++g) {
+        const f32x4 t = *(const f32x4*)(src + ((long)g * pstride + v) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * g + e < C) dst[(long)(4 * g + e) * V + v] = t[e];
+    }
+}
+
+void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, hipStream_t s) {
+    const long V = src.vox();
+    hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s,
+                       tangent ? src.dx : src.x, src.pstride, V, C, dst);
+}
+
+__global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ sx, const float* __restrict__ sdx,
+                                                   long spstride, int SH, int SW, int c, float* __restrict__ dx_,
+                                                   float* __restrict__ ddx, long dpstride, int g0, int G, int D,
+                                                   int H, int W) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long V = (long)D * H * W;
+    if (v >= V) return;
+    const int g = blockIdx.y;
+    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const long sv = ((long)(z + c) * SH + (y + c)) * SW + (x + c);
+    const long so = ((long)g * spstride + sv) * 4, dof = ((long)(g0 + g) * dpstride + v) * 4;
+    *(f32x4*)(dx_ + dof) = *(const f32x4*)(sx + so);
+    if (sdx) *(f32x4*)(ddx + dof) = *(const f32x4*)(sdx + so);
+}
+
+void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s) {
+    const long V = dst.vox();
+    hipLaunchKernelGGL(crop_kernel, dim3((unsigned)((V + 255) / 256), src.G), dim3(256), 0, s, src.x,
+                       vel ? src.dx : nullptr, src.pstride, src.H, src.W, c, dst.x, dst.dx, dst.pstride, g0,
+                       src.G, dst.D, dst.H, dst.W);
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                   long ypstride, int D, int H, int W,
+                                                   const float* __restrict__ xin, long xpstride, int XH, int XW,
+                                                   int c0, int C, float k_dy, float k_x0, OT* __restrict__ disp,
+                                                   OT* __restrict__ velo, int Db, int Hb, int Wb, int a0, int a1,
+                                                   int a2) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long V = (long)D * H * W;
+    if (v >= V) return;
+    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
+    const int yy = rem / W, x = rem - yy * W;
+    const long xv = ((long)(z + c0) * XH + (yy + c0)) * XW + (x + c0);
+    const long bo = ((long)(a0 + z) * Hb + (a1 + yy)) * Wb + (a2 + x);
+    const long bstride = (long)Db * Hb * Wb;
+    for (int g = 0; 4 * g < C; ++g) {
+        const f32x4 yv = *(const f32x4*)(y + ((long)g * ypstride + v) * 4);
+        const f32x4 x0 = *(const f32x4*)(xin + ((long)g * xpstride + xv) * 4);
+        f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+        if (dy) dv = *(const f32x4*)(dy + ((long)g * ypstride + v) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * g + e;
+            if (c < C) {
+                disp[c * bstride + bo] = (OT)((yv[e] + x0[e]) * 6.0f);
+                if (dy) velo[c * bstride + bo] = (OT)(dv[e] * k_dy + x0[e] * k_x0);
+            }
+        }
+    }
+}
+
+void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+                 void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                 hipStream_t s) {
+    const long V = y.vox();
+    const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
+    dim3 grid((unsigned)((V + 255) / 256)), block(256);
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(head_kernel<float>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D, y.H,
+                           y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (float*)disp, (float*)velo,
+                           Db, Hb, Wb, a0, a1, a2);
+    else
+        hipLaunchKernelGGL(head_kernel<_Float16>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D,
+                           y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (_Float16*)disp,
+                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2);
+}
+
+}  // namespace nbe

@@ -1,0 +1,228 @@
+"""Python handle on one libnbe context (one GPU, one stream, one set of weights)."""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LayerDesc, NBEError, check
+
+try:  # torch is optional plumbing: device buffers + streams for resident / multi-GPU runs
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+BLOCKS = ('conv_l00', 'conv_l01', 'down_l0', 'conv_l1', 'down_l1', 'conv_l2', 'down_l2', 'conv_c',
+          'up_r2', 'conv_r2', 'up_r1', 'conv_r1', 'up_r0', 'conv_r00', 'conv_r01')
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def params_fingerprint(params):
+    """Cheap identity of a parameter tree: callers re-assign `.params` after construction
+    (reference tests/test_nbody_emulator.py:807,832), so weights are re-read lazily."""
+    tree = params['params'] if 'params' in params else params
+    fp = []
+    for b in sorted(tree):
+        for l in sorted(tree[b]):
+            for k in sorted(tree[b][l]):
+                a = tree[b][l][k]
+                fp.append((b, l, k, id(a)))
+    return (id(tree), tuple(fp))
+
+
+class Engine:
+    def __init__(self, device=0, in_chan=3, out_chan=3, mid_chan=64, eps=1e-8, compute_vel=True):
+        self._l = _lib.lib()
+        h = C.c_void_p()
+        check(self._l.nbe_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.in_chan, self.out_chan, self.mid_chan = int(in_chan), int(out_chan), int(mid_chan)
+        self.eps, self.compute_vel = float(eps), bool(compute_vel)
+        check(self._l.nbe_set_arch(self._h, self.in_chan, self.out_chan, self.mid_chan, self.eps,
+                                   1 if self.compute_vel else 0))
+        self._keep = None
+        self.loaded = None          # fingerprint of the loaded tree
+        self.premodulated = False
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._l.nbe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_params(self, params, premodulated):
+        if params is None:
+            raise ValueError("No parameters loaded. Use load_params=True in create_emulator.")
+        tree = params['params'] if 'params' in params else params
+        descs, keep = [], []
+        for b in BLOCKS:
+            if b not in tree:
+                raise NBEError("parameter tree is missing block %s" % b)
+            for l, lp in tree[b].items():
+                w = _f32(lp['weight'])
+                bias = _f32(lp['bias'])
+                d = LayerDesc()
+                d.block, d.layer = b.encode(), l.encode()
+                d.cout, d.cin, d.k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+                d.weight, d.bias = w.ctypes.data, bias.ctypes.data
+                keep += [w, bias]
+                if premodulated:
+                    if 'style_weight' in lp:
+                        raise NBEError("%s/%s holds style parameters but a premodulated model was requested" % (b, l))
+                    if self.compute_vel:
+                        if 'dweight' not in lp:
+                            raise NBEError("%s/%s: premodulated velocity parameters need 'dweight'" % (b, l))
+                        dw = _f32(lp['dweight'])
+                        d.dweight = dw.ctypes.data
+                        keep.append(dw)
+                else:
+                    if 'style_weight' not in lp:
+                        raise NBEError("%s/%s has no style parameters; pass premodulated weights to the "
+                                       "NBodyEmulator[Vel]Core models instead" % (b, l))
+                    sw, sb = _f32(lp['style_weight']), _f32(lp['style_bias'])
+                    d.style_weight, d.style_bias = sw.ctypes.data, sb.ctypes.data
+                    keep += [sw, sb]
+                descs.append(d)
+        arr = (LayerDesc * len(descs))(*descs)
+        fn = self._l.nbe_load_premod_weights if premodulated else self._l.nbe_load_style_weights
+        check(fn(self._h, arr, len(descs)))
+        self.loaded = params_fingerprint(params)
+        self.premodulated = bool(premodulated)
+
+    def ensure_params(self, params, premodulated):
+        if params is None:
+            raise ValueError("No parameters loaded. Use load_params=True in create_emulator.")
+        if self.loaded != params_fingerprint(params) or self.premodulated != bool(premodulated):
+            self.load_params(params, premodulated)
+
+    def set_cosmology(self, Om, Dz):
+        check(self._l.nbe_set_cosmology(self._h, float(Om), float(Dz)))
+
+    def set_stream(self, stream_ptr):
+        check(self._l.nbe_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        check(self._l.nbe_synchronize(self._h))
+
+    # ---- compute ------------------------------------------------------------------------------
+    def forward(self, x, Dz, vel_fac=0.0):
+        """x: (C, D, H, W) float32 numpy array or CUDA torch tensor.  Returns disp or (disp, vel)."""
+        Cc, D, H, W = x.shape
+        if Cc != self.in_chan:
+            raise NBEError("input has %d channels, model expects %d" % (Cc, self.in_chan))
+        oshape = (self.out_chan, D - 96, H - 96, W - 96)
+        if min(oshape) <= 0:
+            raise NBEError("input %s is smaller than the receptive field (needs > 96 per axis)" % (tuple(x.shape),))
+        if _is_torch(x):
+            x = x.contiguous().float()
+            disp = torch.empty(oshape, dtype=torch.float32, device=x.device)
+            vel = torch.empty(oshape, dtype=torch.float32, device=x.device) if self.compute_vel else None
+        else:
+            x = _f32(x)
+            disp = np.empty(oshape, np.float32)
+            vel = np.empty(oshape, np.float32) if self.compute_vel else None
+        check(self._l.nbe_forward(self._h, _ptr(x), D, H, W, float(Dz), float(vel_fac), _ptr(disp), _ptr(vel)))
+        return (disp, vel) if self.compute_vel else disp
+
+    def process_box(self, box, size, ndiv, padding, Dz, vel_fac=0.0, out_dtype=np.float32, progress=None,
+                    out=None):
+        size = tuple(int(s) for s in size)
+        if tuple(box.shape) != (self.in_chan,) + size:
+            raise NBEError("input_box shape %s does not match (in_chan,)+size = %s" % (tuple(box.shape), (self.in_chan,) + size))
+        half = np.dtype(out_dtype) == np.float16
+        if not half and np.dtype(out_dtype) != np.float32:
+            raise NBEError("output dtype %s unsupported (float32 / float16)" % np.dtype(out_dtype))
+        oshape = (self.out_chan,) + size
+        if _is_torch(box):
+            box = box.contiguous().float()
+            tdt = torch.float16 if half else torch.float32
+            if out is not None:
+                disp, vel = out
+            else:
+                disp = torch.zeros(oshape, dtype=tdt, device=box.device)
+                vel = torch.zeros(oshape, dtype=tdt, device=box.device) if self.compute_vel else None
+        else:
+            box = _f32(box)
+            disp = np.zeros(oshape, np.float16 if half else np.float32)
+            vel = np.zeros(oshape, disp.dtype) if self.compute_vel else None
+        sz = (C.c_int64 * 3)(*size)
+        nd = (C.c_int * 3)(*[int(n) for n in ndiv])
+        pd = (C.c_int * 6)(*[int(p) for pp in padding for p in pp])
+        cb = _lib.PROGRESS_CB(progress) if progress is not None else C.cast(None, _lib.PROGRESS_CB)
+        check(self._l.nbe_process_box(self._h, _ptr(box), sz, nd, pd, float(Dz), float(vel_fac), _ptr(disp),
+                                      _ptr(vel), 1 if half else 0, cb, None))
+        return (disp, vel) if self.compute_vel else disp
+
+    # ---- test hooks ---------------------------------------------------------------------------
+    def test_layer(self, kind, x, w, bias, dx=None, dw=None, crop=0, act=False, res=None, dres=None):
+        kinds = {'conv3': 0, 'skip': 1, 'down': 2, 'up': 3}
+        k = kinds[kind]
+        x = _f32(x); w = _f32(w); bias = _f32(bias)
+        cin, D, H, W = x.shape
+        cout = w.shape[0]
+        if k == 0: osp = (D - 2, H - 2, W - 2)
+        elif k == 1: osp = (D - 2 * crop, H - 2 * crop, W - 2 * crop)
+        elif k == 2: osp = (D // 2, H // 2, W // 2)
+        else: osp = (2 * D, 2 * H, 2 * W)
+        vel = dw is not None
+        dx = None if dx is None else _f32(dx)
+        dw = None if dw is None else _f32(dw)
+        res = None if res is None else _f32(res)
+        dres = None if dres is None else _f32(dres)
+        y = np.empty((cout,) + osp, np.float32)
+        dy = np.empty_like(y) if vel else None
+        flags = (1 if act else 0) | (2 if res is not None else 0)
+        check(self._l.nbe_test_layer(self._h, k, int(crop), flags, _ptr(x), _ptr(dx), cin, D, H, W, _ptr(w), _ptr(dw),
+                                     _ptr(bias), cout, _ptr(res), _ptr(dres), _ptr(y), _ptr(dy)))
+        return (y, dy) if vel else y
+
+    def test_modulate(self, weight, style_weight, style_bias, s, first_layer, eps=1e-8, vel=True):
+        weight, sw, sb = _f32(weight), _f32(style_weight), _f32(style_bias)
+        cout, cin, k = weight.shape[:3]
+        wn = np.empty_like(weight)
+        dw = np.empty_like(weight) if vel else None
+        check(self._l.nbe_test_modulate(self._h, _ptr(weight), _ptr(sw), _ptr(sb), cout, cin, k, float(s[0]),
+                                        float(s[1]), float(eps), 1 if first_layer else 0, _ptr(wn), _ptr(dw)))
+        return (wn, dw) if vel else wn
+
+    # ---- profiling ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        check(self._l.nbe_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self._l.nbe_profile_reset(self._h))
+
+    def profile_read(self):
+        n = self._l.nbe_profile_count(self._h)
+        out = []
+        for i in range(n):
+            name = C.create_string_buffer(128)
+            ms, la, fl = C.c_double(), C.c_int64(), C.c_double()
+            check(self._l.nbe_profile_entry(self._h, i, name, 128, C.byref(ms), C.byref(la), C.byref(fl)))
+            out.append({'kernel': name.value.decode(), 'ms': ms.value, 'launches': la.value, 'flops': fl.value})
+        return out
+
+    def workspace_bytes(self):
+        return int(self._l.nbe_workspace_bytes(self._h))

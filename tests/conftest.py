@@ -1,0 +1,50 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def engine_factory():
+    """Engines through the C ABI.  On a GPU box a missing libnbe.so is a hard failure, never a skip."""
+    from jax_nbody_emulator_with_dj_amd.engine import Engine
+    made = []
+
+    def make(**kw):
+        e = Engine(**kw)
+        made.append(e)
+        return e
+
+    yield make
+    for e in made:
+        e.close()
+
+
+def rel_l2(a, b):
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def max_over_rms(a, b):
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.sqrt(np.mean(b * b)), 1e-300))

@@ -1,0 +1,79 @@
+"""GPU parity of the whole network (engine level, through the C ABI) against the float64 oracle.
+
+Tolerance: relative L2 <= 2e-5 (displacement), <= 5e-5 (velocity); max|delta|/RMS <= 2e-4.
+Rationale: ~21 sequential float32 contractions with K <= 3456; the float32-vs-float64 envelope of
+the oracle itself on these inputs is ~1e-6 (tests/test_oracle_pins.py)."""
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2, max_over_rms
+
+pytestmark = pytest.mark.gpu
+
+DZ, VF, OM = 0.7731811501855036, 50.537651303131064, 0.3
+
+
+def _check(d, v, d_o, v_o, tag):
+    assert np.all(np.isfinite(d)) and (v is None or np.all(np.isfinite(v)))
+    e = rel_l2(d, d_o), max_over_rms(d, d_o)
+    assert e[0] <= 2e-5 and e[1] <= 2e-4, "%s disp rel_l2=%.3e max/rms=%.3e" % (tag, *e)
+    if v is not None:
+        e = rel_l2(v, v_o), max_over_rms(v, v_o)
+        assert e[0] <= 5e-5 and e[1] <= 2e-4, "%s vel rel_l2=%.3e max/rms=%.3e" % (tag, *e)
+
+
+@pytest.fixture(scope="module")
+def small():
+    from oracle import params as P, model as M
+    rng = np.random.default_rng(5)
+    p = P.synthetic_params(seed=11, mid_chan=8)
+    x = rng.standard_normal((3, 104, 104, 112)).astype(np.float32)
+    d_o, v_o = M.forward(p, x[None], OM, DZ, VF)
+    return p, x, d_o[0], v_o[0]
+
+
+def test_style_vel_small(engine_factory, small):
+    p, x, d_o, v_o = small
+    e = engine_factory(mid_chan=8, compute_vel=True)
+    e.load_params(p, premodulated=False)
+    e.set_cosmology(OM, DZ)
+    d, v = e.forward(x, DZ, VF)
+    assert d.shape == (3, 8, 8, 16)
+    _check(d, v, d_o, v_o, "style-vel mid8")
+    # determinism: bit-identical on repeat (tests/test_nbody_emulator.py:842-863)
+    d2, v2 = e.forward(x, DZ, VF)
+    assert np.array_equal(d, d2) and np.array_equal(v, v2)
+
+
+def test_style_novel_small(engine_factory, small):
+    p, x, d_o, _ = small
+    e = engine_factory(mid_chan=8, compute_vel=False)
+    e.load_params(p, premodulated=False)
+    e.set_cosmology(OM, DZ)
+    d = e.forward(x, DZ)
+    _check(d, None, d_o, None, "style-novel mid8")
+
+
+def test_premod_vel_small(engine_factory, small):
+    from oracle import params as P
+    p, x, d_o, v_o = small
+    pp = P.premodulate_vel(p, 0.5, OM)
+    e = engine_factory(mid_chan=8, compute_vel=True)
+    e.load_params(pp, premodulated=True)
+    d, v = e.forward(x, DZ, VF)
+    _check(d, v, d_o, v_o, "premod-vel mid8")
+
+
+def test_full_width_c1_slice(engine_factory):
+    """mid_chan=64 (production width) on the smallest legal input, against the oracle."""
+    from oracle import params as P, model as M
+    rng = np.random.default_rng(6)
+    p = P.synthetic_params(seed=1234, mid_chan=64)
+    x = rng.standard_normal((3, 104, 104, 104)).astype(np.float32)
+    d_o, v_o = M.forward(p, x[None], OM, DZ, VF)
+    e = engine_factory(mid_chan=64, compute_vel=True)
+    e.load_params(p, premodulated=False)
+    e.set_cosmology(OM, DZ)
+    d, v = e.forward(x, DZ, VF)
+    _check(d, v, d_o[0], v_o[0], "style-vel mid64")
