@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Headline benchmark: output voxels/s of process_box (displacement + velocity) on a 512^3 box,
+ndiv=(4,4,4), StyleNBodyEmulatorVelCore, float32, on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of process_box over the whole box (64 sub-boxes of 224^3 -> 128^3), with the input
+box and the output boxes resident in HBM.  Weights are synthetic (seeded; the pretrained blob is not
+available), which changes neither the FLOPs nor the bytes.  Rank 0 prints ONE JSON line.
+
+N > 1: the sub-box grid is sharded as bricks over the ranks (jax_nbody_emulator_with_dj_amd/sharding.py);
+each rank exchanges its 48-voxel halo with its neighbours over RCCL P2P every step and processes its own
+sub-boxes; total work is fixed (strong scaling).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+Z, OM = 0.5, 0.3
+
+
+def cpu_baseline(threads):
+    """The oracle (NumPy float32 port of the reference path) on the host cores, on a bounded sample:
+    one (1,3,128,128,128) -> 32^3 forward (BASELINE config 1, 4.3 TFLOP)."""
+    from oracle import model as M, params as P, cosmology as C
+    p = P.synthetic_params(seed=1234, mid_chan=64)
+    x = np.random.default_rng(0).standard_normal((1, 3, 128, 128, 128)).astype(np.float32)
+    Dz, vf = float(C.growth_factor(Z, OM)), float(C.vel_norm(Z, OM))
+    t = time.perf_counter()
+    d, v = M.forward(p, x, OM, Dz, vf, dtype=np.float32)
+    dt = time.perf_counter() - t
+    assert np.all(np.isfinite(d)) and np.all(np.isfinite(v))
+    return {"value": 32 ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": "one (1,3,128,128,128)->(1,3,32,32,32) StyleNBodyEmulatorVelCore forward "
+                      "(BASELINE config 1, 4.317 TFLOP), float32 NumPy oracle, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512, help="box side (debug; the headline is 512)")
+    ap.add_argument("--ndiv", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vel", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from jax_nbody_emulator_with_dj_amd import StyleNBodyEmulatorVelCore, StyleNBodyEmulatorCore, cosmology
+    from jax_nbody_emulator_with_dj_amd.engine import Engine
+    from jax_nbody_emulator_with_dj_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed launch with that many ranks" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    vel = not args.no_vel
+    model = (StyleNBodyEmulatorVelCore if vel else StyleNBodyEmulatorCore)()
+    params = model.init(1234)
+    eng = Engine(device=local_rank, compute_vel=vel)
+    eng.load_params(params, premodulated=False)
+    Dz = float(np.float32(cosmology.growth_factor(Z, OM)))
+    vf = float(np.float32(cosmology.vel_norm(Z, OM)))
+    eng.set_cosmology(OM, Dz)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    N = args.size
+    size, ndiv = (N, N, N), (args.ndiv,) * 3
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    if world == 1:
+        box = torch.randn((3,) + size, device=dev, dtype=torch.float32, generator=gen)
+        disp = torch.zeros_like(box)
+        velo = torch.zeros_like(box) if vel else None
+
+        def step():
+            eng.process_box(box, size, ndiv, ((48, 48),) * 3, Dz, vf, out=(disp, velo))
+    else:
+        sb = sharding.ShardedBox(eng, size, ndiv, rank, world, comm_stream=torch.cuda.Stream(device=dev))
+        brick = torch.randn((3,) + sb.bshape, device=dev, dtype=torch.float32, generator=gen)
+        disp = torch.zeros_like(brick)
+        velo = torch.zeros_like(brick) if vel else None
+
+        def step():
+            sb.process(brick, Dz, vf, disp, velo)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+    prof = eng.profile_read()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = bool(torch.isfinite(disp).all().item()) and (velo is None or bool(torch.isfinite(velo).all().item()))
+
+    if rank == 0:
+        vox = float(N) ** 3 * args.steps
+        out = {
+            "metric": "voxels/sec (disp+vel) on 512^3 box, ndiv=4" if vel else "voxels/sec (disp only)",
+            "value": vox / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "process_box %d^3 ndiv=(%d,%d,%d) compute_vel=%s StyleNBodyEmulator%sCore, "
+                                   "synthetic seeded weights, box resident in HBM" % (N, *ndiv, vel, "Vel" if vel else ""),
+                       "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,)},
+            "finite": ok,
+        }
+        # roofline of the dominant kernel, from HIP events recorded on the engine's stream inside the timed region
+        if prof:
+            dom = max(prof, key=lambda e: e["ms"])
+            tot_ms = sum(e["ms"] for e in prof)
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
+                               "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
+            out["kernels"] = [{"kernel": e["kernel"], "ms": round(e["ms"], 3), "launches": e["launches"],
+                               "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
+                              for e in sorted(prof, key=lambda e: -e["ms"])]
+        if world == 1 and not args.no_cpu_baseline:
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,16 @@ int nbe_process_box(nbe_ctx* ctx, const void* box, const int64_t size[3], const 
                     float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
                     nbe_progress_cb cb, void* user);
 
+/* The same loop over a sub-set of the sub-boxes of a REGION of a periodic box (multi-GPU sharding: each
+ * rank owns a brick).  Sub-boxes tile [origin, origin+region) with `ndiv`; `order`
+ * (nullable) lists the sub-box indices to run, in order; results go to an output array of spatial size
+ * out_size at out_origin + anchor.  Outputs are NOT zero-initialised here.  No reference counterpart:
+ * the reference loop (subbox.py:195-215) is serial on one device. */
+int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3], const int64_t origin[3],
+                       const int64_t region[3], const int ndiv[3], const int* order, int norder,
+                       float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
+                       const int64_t out_size[3], const int64_t out_origin[3]);
+
 /* growth_factor / vel_norm (cosmology.py:34-40, :130-141) in double precision on the host. */
 double nbe_growth_factor(double z, double Om);
 double nbe_vel_norm(double z, double Om);

@@ -48,6 +48,10 @@ SIGNATURES = {
     "nbe_process_box": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                   PROGRESS_CB, C.c_void_p]),
+    "nbe_process_region": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "nbe_growth_factor": (C.c_double, [C.c_double, C.c_double]),
     "nbe_vel_norm": (C.c_double, [C.c_double, C.c_double]),
     "nbe_test_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

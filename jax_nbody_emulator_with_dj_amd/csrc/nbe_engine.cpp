@@ -621,27 +621,31 @@ int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float 
     return 0;
 }
 
-int nbe_process_box(nbe_ctx* c, const void* box, const int64_t size[3], const int ndiv[3], const int pad[6],
-                    float Dz, float vel_fac, void* disp, void* vel, int out_dtype, nbe_progress_cb cb, void* user) {
-    if (!c || !box || !disp || !size || !ndiv || !pad) return fail("null argument");
+// Sub-boxes tiling the region [origin, origin + region) of a periodic box; results are written into an
+// output array of spatial size `osize` at `oorigin` + the sub-box anchor inside the region.
+static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], const int64_t origin[3],
+                          const int64_t region[3], const int ndiv[3], const int* order, int norder,
+                          float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
+                          const int64_t osize[3], const int64_t oorigin[3], bool zero_out,
+                          nbe_progress_cb cb, void* user) {
     if (require_ready(c)) return 1;
     if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
     if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
-    for (int i = 0; i < 6; ++i)
-        if (pad[i] != 48) return fail("padding must be 48 on every side (receptive field of the network, subbox.py:43); got %d", pad[i]);
     for (int i = 0; i < 3; ++i) {
-        if (ndiv[i] < 1 || size[i] < 1) return fail("size and ndiv must be positive");
-        if (size[i] > 2000000000LL / 4) return fail("box axis too large");
+        if (ndiv[i] < 1 || bsize[i] < 1 || region[i] < 1 || osize[i] < 1) return fail("sizes and ndiv must be positive");
+        if (bsize[i] > 2000000000LL / 4 || osize[i] > 2000000000LL / 4) return fail("box axis too large");
     }
-    const int S0 = (int)size[0], S1 = (int)size[1], S2 = (int)size[2];
-    const int c0 = S0 / ndiv[0], c1 = S1 / ndiv[1], c2 = S2 / ndiv[2];                    // subbox.py:49 (floor)
+    const int S0 = (int)bsize[0], S1 = (int)bsize[1], S2 = (int)bsize[2];
+    const int O0 = (int)osize[0], O1 = (int)osize[1], O2 = (int)osize[2];
+    const int c0 = (int)(region[0] / ndiv[0]), c1 = (int)(region[1] / ndiv[1]), c2 = (int)(region[2] / ndiv[2]);   // subbox.py:49 (floor)
     const int D = c0 + 96, H = c1 + 96, W = c2 + 96;
     if (check_dims(D, H, W)) return 1;
+    for (int i = 0; i < 3; ++i)
+        if (oorigin[i] < 0 || oorigin[i] + region[i] > osize[i]) return fail("output region does not fit the output array");
     HIPCHK(hipSetDevice(c->device));
-    const int64_t nvox = (int64_t)S0 * S1 * S2;
-    const int64_t in_bytes = nvox * c->in_chan * 4;
+    const int64_t in_bytes = (int64_t)S0 * S1 * S2 * c->in_chan * 4;
     const int esz = out_dtype == NBE_F16 ? 2 : 4;
-    const int64_t out_bytes = nvox * c->out_chan * esz;
+    const int64_t out_bytes = (int64_t)O0 * O1 * O2 * c->out_chan * esz;
     const bool in_dev = is_device_ptr(box), out_dev = is_device_ptr(disp);
     if (ensure_workspace(c, D, H, W)) return 1;
     const float* bd = (const float*)box;
@@ -659,17 +663,21 @@ int nbe_process_box(nbe_ctx* c, const void* box, const int64_t size[3], const in
         dd = c->box_out; vd = c->box_out + out_bytes;
     }
     // subbox.py:168-170: outputs start as zeros (voxels beyond ndiv*crop_size stay zero)
-    if ((int64_t)c0 * ndiv[0] != S0 || (int64_t)c1 * ndiv[1] != S1 || (int64_t)c2 * ndiv[2] != S2 || !out_dev) {
+    if (zero_out || !out_dev) {
         HIPCHK(hipMemsetAsync(dd, 0, out_bytes, c->stream));
         if (c->vel) HIPCHK(hipMemsetAsync(vd, 0, out_bytes, c->stream));
     }
     const int total = ndiv[0] * ndiv[1] * ndiv[2];
-    for (int idx = 0; idx < total; ++idx) {
+    const int n = order ? norder : total;
+    for (int k = 0; k < n; ++k) {
+        const int idx = order ? order[k] : k;
+        if (idx < 0 || idx >= total) return fail("sub-box index %d out of range (0..%d)", idx, total - 1);
         // subbox.py:60-66: row-major over ndiv, last axis fastest
         const int a0 = (idx / (ndiv[1] * ndiv[2])) * c0, a1 = ((idx / ndiv[2]) % ndiv[1]) * c1, a2 = (idx % ndiv[2]) * c2;
-        if (run_subbox(c, bd, S0, S1, S2, a0 - 48, a1 - 48, a2 - 48, D, H, W, Dz, vel_fac, dd, vd, out_dtype,
-                       S0, S1, S2, a0, a1, a2)) return 1;
-        if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb(idx + 1, total, user); }
+        if (run_subbox(c, bd, S0, S1, S2, (int)origin[0] + a0 - 48, (int)origin[1] + a1 - 48, (int)origin[2] + a2 - 48,
+                       D, H, W, Dz, vel_fac, dd, vd, out_dtype, O0, O1, O2,
+                       (int)oorigin[0] + a0, (int)oorigin[1] + a1, (int)oorigin[2] + a2)) return 1;
+        if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb(k + 1, n, user); }
     }
     HIPCHK(hipGetLastError());
     if (!out_dev) {
@@ -678,6 +686,25 @@ int nbe_process_box(nbe_ctx* c, const void* box, const int64_t size[3], const in
     }
     if (!out_dev || !in_dev) HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int nbe_process_box(nbe_ctx* c, const void* box, const int64_t size[3], const int ndiv[3], const int pad[6],
+                    float Dz, float vel_fac, void* disp, void* vel, int out_dtype, nbe_progress_cb cb, void* user) {
+    if (!c || !box || !disp || !size || !ndiv || !pad) return fail("null argument");
+    for (int i = 0; i < 6; ++i)
+        if (pad[i] != 48) return fail("padding must be 48 on every side (receptive field of the network, subbox.py:43); got %d", pad[i]);
+    const int64_t zero[3] = {0, 0, 0};
+    return process_region(c, box, size, zero, size, ndiv, nullptr, 0, Dz, vel_fac, disp, vel, out_dtype, size, zero,
+                          true, cb, user);
+}
+
+int nbe_process_region(nbe_ctx* c, const void* box, const int64_t box_size[3], const int64_t origin[3],
+                       const int64_t region[3], const int ndiv[3], const int* order, int norder,
+                       float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
+                       const int64_t out_size[3], const int64_t out_origin[3]) {
+    if (!c || !box || !disp || !box_size || !origin || !region || !ndiv || !out_size || !out_origin) return fail("null argument");
+    return process_region(c, box, box_size, origin, region, ndiv, order, norder, Dz, vel_fac, disp, vel, out_dtype,
+                          out_size, out_origin, false, nullptr, nullptr);
 }
 
 // ---- test hooks -----------------------------------------------------------------------------------

@@ -175,6 +175,22 @@ class Engine:
                                       _ptr(vel), 1 if half else 0, cb, None))
         return (disp, vel) if self.compute_vel else disp
 
+    def process_region(self, box, origin, region, ndiv, Dz, vel_fac, disp, vel, out_origin=(0, 0, 0), order=None):
+        """Run (a subset of) the sub-boxes tiling `region` of the periodic array `box` (CUDA tensors);
+        results land in disp / vel (CUDA tensors) at out_origin + anchor.  Asynchronous on the engine's stream."""
+        i64 = lambda t: (C.c_int64 * 3)(*[int(v) for v in t])
+        half = disp.element_size() == 2
+        nd = (C.c_int * 3)(*[int(n) for n in ndiv])
+        if order is not None:
+            oarr = (C.c_int * len(order))(*[int(o) for o in order])
+            if len(order) == 0:
+                return
+        else:
+            oarr = None
+        check(self._l.nbe_process_region(self._h, _ptr(box), i64(box.shape[1:]), i64(origin), i64(region), nd,
+                                         oarr, 0 if order is None else len(order), float(Dz), float(vel_fac),
+                                         _ptr(disp), _ptr(vel), 1 if half else 0, i64(disp.shape[1:]), i64(out_origin)))
+
     # ---- test hooks ---------------------------------------------------------------------------
     def test_layer(self, kind, x, w, bias, dx=None, dw=None, crop=0, act=False, res=None, dres=None):
         kinds = {'conv3': 0, 'skip': 1, 'down': 2, 'up': 3}
