@@ -37,9 +37,11 @@ def cpu_baseline(threads):
     p = P.synthetic_params(seed=1234, mid_chan=64)
     x = np.random.default_rng(0).standard_normal((1, 3, 128, 128, 128)).astype(np.float32)
     Dz, vf = float(C.growth_factor(Z, OM)), float(C.vel_norm(Z, OM))
-    t = time.perf_counter()
-    d, v = M.forward(p, x, OM, Dz, vf, dtype=np.float32)
-    dt = time.perf_counter() - t
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=threads):
+        t = time.perf_counter()
+        d, v = M.forward(p, x, OM, Dz, vf, dtype=np.float32)
+        dt = time.perf_counter() - t
     assert np.all(np.isfinite(d)) and np.all(np.isfinite(v))
     return {"value": 32 ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
             "sample": "one (1,3,128,128,128)->(1,3,32,32,32) StyleNBodyEmulatorVelCore forward "
@@ -55,6 +57,9 @@ def main():
     ap.add_argument("--ndiv", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vel", action="store_true")
+    ap.add_argument("--max-tile", type=int, default=256,
+                    help="internal tile edge: sub-boxes are merged into tiles up to this size when that is exact "
+                         "(crop %% 8 == 0); 0 = run the caller's 64 sub-boxes of 224^3 one by one")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +91,7 @@ def main():
     Dz = float(np.float32(cosmology.growth_factor(Z, OM)))
     vf = float(np.float32(cosmology.vel_norm(Z, OM)))
     eng.set_cosmology(OM, Dz)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_max_tile(args.max_tile)
 
     N = args.size
     size, ndiv = (N, N, N), (args.ndiv,) * 3
@@ -140,7 +145,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "process_box %d^3 ndiv=(%d,%d,%d) compute_vel=%s StyleNBodyEmulator%sCore, "
                                    "synthetic seeded weights, box resident in HBM" % (N, *ndiv, vel, "Vel" if vel else ""),
-                       "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,)},
+                       "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,),
+                       "internal_tiles": "%s tiles per %s" % (
+                           (eng.plan_tiles(size, ndiv) if world == 1 else eng.plan_tiles(sb.bshape, sb.nd_local)),
+                           "box" if world == 1 else "rank brick")},
             "finite": ok,
         }
         # roofline of the dominant kernel, from HIP events recorded on the engine's stream inside the timed region
@@ -156,7 +164,8 @@ def main():
                                "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
                               for e in sorted(prof, key=lambda e: -e["ms"])]
         if world == 1 and not args.no_cpu_baseline:
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = min(avail, 16)        # the 1-GPU box's CPU share; more BLAS threads only oversubscribe
             out["cpu_baseline"] = cpu_baseline(threads)
         print(json.dumps(out), flush=True)
     if world > 1:

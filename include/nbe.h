@@ -92,6 +92,15 @@ int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3],
                        float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
                        const int64_t out_size[3], const int64_t out_origin[3]);
 
+/* Internal tiling.  When crop_size = size/ndiv is a multiple of 8 on every axis, all crop origins keep the
+ * phase of the network's 2^3 stride lattice, so the per-voxel result does not depend on how the box is cut
+ *  and neighbouring sub-boxes can be merged into larger tiles that recompute less halo
+ * (17.1 MFLOP/voxel at 128^3 crops, 11.2 at 256^3).  nbe_plan_tiles returns the grid nbe_process_box will
+ * actually run: per axis the largest merge with tile edge <= max_tile; unchanged when crop % 8 != 0.
+ * nbe_set_max_tile(ctx, 0) keeps the caller's grid exactly (default 256, or env NBE_MAX_TILE). */
+int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int out_ndiv[3]);
+int nbe_set_max_tile(nbe_ctx* ctx, int max_tile);
+
 /* growth_factor / vel_norm (cosmology.py:34-40, :130-141) in double precision on the host. */
 double nbe_growth_factor(double z, double Om);
 double nbe_vel_norm(double z, double Om);

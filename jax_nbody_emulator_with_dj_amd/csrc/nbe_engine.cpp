@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -91,6 +92,7 @@ struct nbe_ctx {
     char* ws = nullptr;
     int64_t ws_bytes = 0;
     bool dry = false;
+    int max_tile = 256;                           // internal tile edge (output voxels); 0 = caller's grid as given
     // device-resident boxes of process_box
     float* box_in = nullptr; int64_t box_in_bytes = 0;
     char* box_out = nullptr; int64_t box_out_bytes = 0;
@@ -516,6 +518,7 @@ int nbe_create(int device_id, nbe_ctx** out) {
     c->device = device_id;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    if (const char* e = getenv("NBE_MAX_TILE")) c->max_tile = atoi(e) > 0 ? atoi(e) : 0;
     *out = c;
     return 0;
 }
@@ -623,8 +626,37 @@ int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float 
 
 // Sub-boxes tiling the region [origin, origin + region) of a periodic box; results are written into an
 // output array of spatial size `osize` at `oorigin` + the sub-box anchor inside the region.
+int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int out_ndiv[3]) {
+    if (!region || !ndiv || !out_ndiv) return fail("null argument");
+    bool ok = max_tile > 0;
+    for (int a = 0; a < 3 && ok; ++a) {
+        if (ndiv[a] < 1 || region[a] < 1) return fail("sizes and ndiv must be positive");
+        const int64_t crop = region[a] / ndiv[a];
+        // merging is exact only when every anchor keeps the 2^3 stride lattice phase (crop % 8 == 0)
+        // and nothing is left over (subbox.py:49 floors; the remainder stays zero)
+        if (crop % 8 != 0 || crop * ndiv[a] != region[a]) ok = false;
+    }
+    for (int a = 0; a < 3; ++a) {
+        out_ndiv[a] = ndiv[a];
+        if (!ok) continue;
+        const int64_t crop = region[a] / ndiv[a];
+        int best = 1;
+        for (int m = 1; m <= ndiv[a]; ++m)
+            if (ndiv[a] % m == 0 && crop * m <= max_tile) best = m;
+        out_ndiv[a] = ndiv[a] / best;
+    }
+    return 0;
+}
+
+int nbe_set_max_tile(nbe_ctx* c, int max_tile) {
+    if (!c) return fail("null context");
+    if (max_tile < 0) return fail("max_tile must be >= 0 (0 = keep the caller's sub-box grid)");
+    c->max_tile = max_tile;
+    return 0;
+}
+
 static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], const int64_t origin[3],
-                          const int64_t region[3], const int ndiv[3], const int* order, int norder,
+                          const int64_t region[3], const int ndiv_in[3], const int* order, int norder,
                           float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
                           const int64_t osize[3], const int64_t oorigin[3], bool zero_out,
                           nbe_progress_cb cb, void* user) {
@@ -632,11 +664,23 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
     if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
     for (int i = 0; i < 3; ++i) {
-        if (ndiv[i] < 1 || bsize[i] < 1 || region[i] < 1 || osize[i] < 1) return fail("sizes and ndiv must be positive");
+        if (ndiv_in[i] < 1 || bsize[i] < 1 || region[i] < 1 || osize[i] < 1) return fail("sizes and ndiv must be positive");
         if (bsize[i] > 2000000000LL / 4 || osize[i] > 2000000000LL / 4) return fail("box axis too large");
     }
     const int S0 = (int)bsize[0], S1 = (int)bsize[1], S2 = (int)bsize[2];
     const int O0 = (int)osize[0], O1 = (int)osize[1], O2 = (int)osize[2];
+    // Internal tiling: with an explicit sub-box list the caller's grid is used as given; otherwise adjacent
+    // sub-boxes may be merged into larger tiles (nbe_plan_tiles) -- identical results, less halo recompute.
+    int ndiv_eff[3] = {ndiv_in[0], ndiv_in[1], ndiv_in[2]};
+    if (!order && c->max_tile > 0) {
+        if (nbe_plan_tiles(region, ndiv_in, c->max_tile, ndiv_eff)) return 1;
+        // fall back to the caller's grid when the merged tile's workspace cannot be allocated
+        if (ndiv_eff[0] != ndiv_in[0] || ndiv_eff[1] != ndiv_in[1] || ndiv_eff[2] != ndiv_in[2]) {
+            const int d = (int)(region[0] / ndiv_eff[0]) + 96, h = (int)(region[1] / ndiv_eff[1]) + 96, w = (int)(region[2] / ndiv_eff[2]) + 96;
+            if (ensure_workspace(c, d, h, w)) { ndiv_eff[0] = ndiv_in[0]; ndiv_eff[1] = ndiv_in[1]; ndiv_eff[2] = ndiv_in[2]; (void)hipGetLastError(); }
+        }
+    }
+    const int* ndiv = ndiv_eff;
     const int c0 = (int)(region[0] / ndiv[0]), c1 = (int)(region[1] / ndiv[1]), c2 = (int)(region[2] / ndiv[2]);   // subbox.py:49 (floor)
     const int D = c0 + 96, H = c1 + 96, W = c2 + 96;
     if (check_dims(D, H, W)) return 1;

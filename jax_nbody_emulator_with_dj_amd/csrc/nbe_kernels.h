@@ -29,7 +29,7 @@ inline constexpr int mode_ck(int mode) { return mode == MODE_FLAT3 ? 8 : 16; }
 
 // One packed weight set (see pack_index in nbe_kernels.hip for the layout).
 struct PackedW {
-    float* w = nullptr;      // [ct][stage][tap][CK/4][COUT_T][4]
+    float* w = nullptr;      // [ct][stage = chunk*nseg + seg][tap][CK/4][COUT_T][4]
     float* dw = nullptr;
     float* bias = nullptr;   // padded to ct*COUT_T
     int mode = 0, ni = 2;    // COUT_T = 32*ni

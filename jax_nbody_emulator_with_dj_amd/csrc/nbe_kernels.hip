@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
     }
 
     auto issue = [&](int s, int b) {
-        const int seg = s / nchunk, chunk = s - seg * nchunk;
+        // channel chunk outer, (dz,dy) segment inner: the 9 segments of one 8-channel slab are fetched back to
+        // back, so the rows shared between segments and between neighbouring tiles are still in the XCD's L2
+        const int chunk = s / mode_nseg(MODE), seg = s - chunk * mode_nseg(MODE);
         long segoff;
         if (MODE == MODE_FLAT3) segoff = (seg / 3) * HW + (seg % 3) * a.W;
         else if (MODE == MODE_DOWN) segoff = (seg >> 2) * HW + ((seg >> 1) & 1) * a.W + (seg & 1);
@@ -340,7 +342,7 @@ void launch_modulate(const float* weight, const float* style_weight, const float
                        cin, k3, s0, s1, eps, first_layer, w_n, dw_tot);
 }
 
-// packed layout: [set][ct][stage = seg*nchunk + chunk][tap][gl][co][e]; channel = chunk*CK + gl*4 + e
+// packed layout: [set][ct][stage = chunk*nseg + seg][tap][gl][co][e]; channel = chunk*CK + gl*4 + e
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, int cout, int cin, int kind,
                                                    int mode, int ni, int nchunk, long floats_per_set,
                                                    int nsets, float* __restrict__ dst) {
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
     const long per_set_ct = floats_per_set / ((long)nstage * TAPS * GL * COUT_T * 4);
     const int ct = (int)(r % per_set_ct); r /= per_set_ct;
     const int set = (int)r;
-    const int seg = stage / nchunk, chunk = stage - seg * nchunk;
+    const int chunk = stage / mode_nseg(mode), seg = stage - chunk * mode_nseg(mode);
     const int ci = chunk * CK + gl * 4 + e;
     const int oc = ct * COUT_T + co;
     int k, kz, ky, kx;

@@ -123,8 +123,32 @@ class Engine:
     def set_stream(self, stream_ptr):
         check(self._l.nbe_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
+    def set_max_tile(self, max_tile):
+        """0 = run exactly the caller's sub-box grid; N = merge sub-boxes into tiles of edge <= N."""
+        check(self._l.nbe_set_max_tile(self._h, int(max_tile)))
+        self.max_tile = int(max_tile)
+
+    def plan_tiles(self, region, ndiv):
+        """The sub-box grid the engine will actually run for `region` cut by `ndiv` (nbe_plan_tiles)."""
+        import os
+        mt = getattr(self, 'max_tile', None)
+        if mt is None:
+            mt = int(os.environ.get("NBE_MAX_TILE", "256"))
+        out = (C.c_int * 3)()
+        check(self._l.nbe_plan_tiles((C.c_int64 * 3)(*[int(r) for r in region]), (C.c_int * 3)(*[int(n) for n in ndiv]),
+                                     max(mt, 0), out))
+        return tuple(out)
+
     def synchronize(self):
         check(self._l.nbe_synchronize(self._h))
+
+    def _follow_torch_stream(self):
+        """CUDA tensors in/out: enqueue on torch's current stream so that torch ops before and after
+        this call are ordered with the kernels (device pointers make the C calls asynchronous)."""
+        sp = torch.cuda.current_stream().cuda_stream
+        if getattr(self, '_stream_ptr', None) != sp:
+            self.set_stream(sp)
+            self._stream_ptr = sp
 
     # ---- compute ------------------------------------------------------------------------------
     def forward(self, x, Dz, vel_fac=0.0):
@@ -136,6 +160,7 @@ class Engine:
         if min(oshape) <= 0:
             raise NBEError("input %s is smaller than the receptive field (needs > 96 per axis)" % (tuple(x.shape),))
         if _is_torch(x):
+            self._follow_torch_stream()
             x = x.contiguous().float()
             disp = torch.empty(oshape, dtype=torch.float32, device=x.device)
             vel = torch.empty(oshape, dtype=torch.float32, device=x.device) if self.compute_vel else None
@@ -156,6 +181,7 @@ class Engine:
             raise NBEError("output dtype %s unsupported (float32 / float16)" % np.dtype(out_dtype))
         oshape = (self.out_chan,) + size
         if _is_torch(box):
+            self._follow_torch_stream()
             box = box.contiguous().float()
             tdt = torch.float16 if half else torch.float32
             if out is not None:
@@ -178,6 +204,7 @@ class Engine:
     def process_region(self, box, origin, region, ndiv, Dz, vel_fac, disp, vel, out_origin=(0, 0, 0), order=None):
         """Run (a subset of) the sub-boxes tiling `region` of the periodic array `box` (CUDA tensors);
         results land in disp / vel (CUDA tensors) at out_origin + anchor.  Asynchronous on the engine's stream."""
+        self._follow_torch_stream()
         i64 = lambda t: (C.c_int64 * 3)(*[int(v) for v in t])
         half = disp.element_size() == 2
         nd = (C.c_int * 3)(*[int(n) for n in ndiv])

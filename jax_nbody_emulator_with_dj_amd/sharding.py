@@ -146,7 +146,9 @@ class ShardedBox:
         """brick, disp, vel: CUDA tensors (C, *bshape).  Interior sub-boxes run while the halo
         messages are in flight on the communication stream; boundary sub-boxes wait for them."""
         cur = torch.cuda.current_stream()
-        interior, boundary = split_interior(self.nd_local, self.bshape)
+        # the engine merges sub-boxes into larger tiles when that is exact (nbe_plan_tiles); split on that grid
+        nd = self.eng.plan_tiles(self.bshape, self.nd_local)
+        interior, boundary = split_interior(nd, self.bshape)
         if self.comm_stream is not None and interior:
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
@@ -154,12 +156,12 @@ class ShardedBox:
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
             # interior crops read the un-haloed brick itself (origin 0): independent of H
-            self.eng.process_region(brick, (0, 0, 0), self.bshape, self.nd_local, Dz, vel_fac, disp, vel, order=interior)
+            self.eng.process_region(brick, (0, 0, 0), self.bshape, nd, Dz, vel_fac, disp, vel, order=interior)
             cur.wait_event(done)
             H.record_stream(cur)
         else:
             H = exchange_halo(brick, self.grid, self.coords, PAD, self.group)
             boundary = interior + boundary
-        self.eng.process_region(H, (PAD, PAD, PAD), self.bshape, self.nd_local, Dz, vel_fac, disp, vel,
+        self.eng.process_region(H, (PAD, PAD, PAD), self.bshape, nd, Dz, vel_fac, disp, vel,
                                 order=sorted(boundary))
         return disp, vel

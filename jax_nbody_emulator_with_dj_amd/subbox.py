@@ -138,7 +138,8 @@ class SubboxProcessor:
                 from tqdm import tqdm
                 bar = tqdm(total=int(cfg.n_subboxes), desc=desc, ncols=80,
                            bar_format='{desc}: {percentage:3.0f}%|{bar:30}| {n_fmt}/{total_fmt} [{elapsed}<{remaining}]')
-                cb = lambda done, total, user: bar.update(done - bar.n)
+                nsub = int(cfg.n_subboxes)      # the engine may merge sub-boxes into fewer, larger tiles
+                cb = lambda done, total, user: bar.update(int(round(done * nsub / max(total, 1))) - bar.n)
             except Exception:
                 bar = None
         try:

@@ -1,0 +1,188 @@
+"""GPU parity through the drop-in Python API (create_emulator / model.apply / process_box -> C ABI),
+against the committed golden fixtures (float64 oracle outputs) and, at BASELINE sizes, through
+size-independent properties.
+
+Tolerances: relative L2 <= 2e-5 (disp), 5e-5 (vel); max|delta|/RMS <= 2e-4 (float32 MFMA vs float64)."""
+
+import os
+
+import numpy as np
+import pytest
+
+import jax_nbody_emulator_with_dj_amd as J
+from conftest import rel_l2, max_over_rms
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+Z, OM = 0.5, 0.3
+
+
+def _synthetic(seed, mid):
+    # same generator as oracle/params.py:synthetic_params (kept in step by test_golden_inputs_reproducible)
+    from oracle import params as P
+    return P.synthetic_params(seed=seed, mid_chan=mid)
+
+
+def _close(got, want, l2, mx, tag):
+    assert got.shape == want.shape and np.all(np.isfinite(got)), tag
+    e = rel_l2(got, want), max_over_rms(got, want)
+    assert e[0] <= l2 and e[1] <= mx, "%s: rel_l2=%.3e max/rms=%.3e" % (tag, *e)
+
+
+@pytest.mark.parametrize("tag", ["net8", "net64"])
+def test_apply_matches_golden(tag):
+    seed_p, seed_x, mid, d0, d1, d2 = (int(v) for v in GOLD[tag + "_meta"])
+    p = _synthetic(seed_p, mid)
+    x = np.random.default_rng(seed_x).standard_normal((1, 3, d0, d1, d2)).astype(np.float32)
+    Dz, vf = J.growth_factor(Z, OM), J.vel_norm(Z, OM)
+    model = J.StyleNBodyEmulatorVelCore(mid_chan=mid)
+    d, v = model.apply(p, x, np.array([OM]), np.atleast_1d(Dz), np.atleast_1d(vf))
+    assert d.dtype == np.float32 and d.shape == (1, 3, d0 - 96, d1 - 96, d2 - 96)
+    _close(d[0], GOLD[tag + "_disp"], 2e-5, 2e-4, tag + " disp")
+    _close(v[0], GOLD[tag + "_vel"], 5e-5, 2e-4, tag + " vel")
+    # premodulated twin through the package's own tree walker (nbody_emulator.py:221-266)
+    pp = J.modulate_emulator_parameters_vel(p, Z, OM)
+    d2_, v2_ = J.NBodyEmulatorVelCore(mid_chan=mid).apply(pp, x, np.atleast_1d(Dz), np.atleast_1d(vf))
+    _close(d2_[0], GOLD[tag + "_disp"], 2e-5, 2e-4, tag + " premod disp")
+    _close(v2_[0], GOLD[tag + "_vel"], 5e-5, 2e-4, tag + " premod vel")
+    # displacement-only twins
+    d3 = J.StyleNBodyEmulatorCore(mid_chan=mid).apply(p, x, np.array([OM]), np.atleast_1d(Dz))
+    _close(d3[0], GOLD[tag + "_disp"], 2e-5, 2e-4, tag + " novel disp")
+    pn = J.modulate_emulator_parameters(p, Z, OM)
+    d4 = J.NBodyEmulatorCore(mid_chan=mid).apply(pn, x, np.atleast_1d(Dz))
+    _close(d4[0], GOLD[tag + "_disp"], 2e-5, 2e-4, tag + " premod novel disp")
+
+
+def test_process_box_matches_golden_and_reference_semantics():
+    seed_p, seed_x, mid, s0, s1, s2, n0, n1, n2 = (int(v) for v in GOLD["pbox_meta"])
+    p = _synthetic(seed_p, mid)
+    box = np.random.default_rng(seed_x).standard_normal((3, s0, s1, s2)).astype(np.float32)
+    keep = box.copy()
+    cfg = J.SubboxConfig(size=(s0, s1, s2), ndiv=(n0, n1, n2))
+    emu = J.create_emulator(load_params=False, processor_config=cfg, mid_chan=mid)
+    emu.params = p
+    emu.processor.params = p                                   # callers assign after construction
+    dis, vel = emu.process_box(box, Z, OM, show_progress=False)
+    assert dis.dtype == np.float32 and dis.shape == (3, s0, s1, s2)
+    np.testing.assert_array_equal(box, keep)                   # input preserved (tests/test_subbox.py:331-340)
+    _close(dis, GOLD["pbox_disp"], 2e-5, 2e-4, "process_box disp")
+    _close(vel, GOLD["pbox_vel"], 5e-5, 2e-4, "process_box vel")
+    dis2, vel2 = emu.process_box(box, Z, OM, show_progress=True, desc="again")
+    assert np.array_equal(dis, dis2) and np.array_equal(vel, vel2)      # deterministic, bit for bit
+    # different redshift -> different output (tests/test_subbox.py:342-360)
+    dis3, _ = emu.process_box(box, 0.0, OM, show_progress=False)
+    assert not np.allclose(dis3, dis)
+    # float16 outputs (tests/test_subbox.py:690-786)
+    cfg16 = J.SubboxConfig(size=(s0, s1, s2), ndiv=(n0, n1, n2), output_dtype=np.float16)
+    emu16 = J.create_emulator(load_params=False, processor_config=cfg16, mid_chan=mid)
+    emu16.processor.params = p
+    d16, v16 = emu16.process_box(box, Z, OM, show_progress=False)
+    assert d16.dtype == np.float16 and v16.dtype == np.float16
+    np.testing.assert_allclose(d16.astype(np.float32), dis, rtol=2e-3, atol=2e-3)
+
+
+def test_trailing_voxels_stay_zero():
+    """size % ndiv != 0: crop_size floors and the remainder is never written (subbox.py:49, :168-170)."""
+    p = _synthetic(3, 8)
+    box = np.random.default_rng(0).standard_normal((3, 17, 8, 8)).astype(np.float32)
+    cfg = J.SubboxConfig(size=(17, 8, 8), ndiv=(2, 1, 1))
+    emu = J.create_emulator(load_params=False, processor_config=cfg, mid_chan=8, compute_vel=False)
+    emu.processor.params = p
+    dis = emu.process_box(box, Z, OM, show_progress=False)
+    assert np.all(dis[:, 16:] == 0) and np.all(np.abs(dis[:, :16]).sum(axis=(0, 2, 3)) > 0)
+
+
+def test_config2_properties_at_full_size():
+    """BASELINE config 2: 128^3 box, ndiv=(1,1,1), compute_vel=False, production width.  Checked through
+    size-independent properties: periodic translation equivariance (shifts that are multiples of 8, the
+    period of the three stride-2 levels) and independence of ndiv when crop_size % 8 == 0."""
+    m = J.StyleNBodyEmulatorCore()
+    p = m.init(1234)
+    box = np.random.default_rng(0).standard_normal((3, 128, 128, 128)).astype(np.float32)
+    cfg = J.SubboxConfig(size=(128,) * 3, ndiv=(1, 1, 1))
+    emu = J.create_emulator(load_params=False, processor_config=cfg, compute_vel=False)
+    emu.processor.params = p
+    d1 = emu.process_box(box, Z, OM, show_progress=False)
+    assert np.all(np.isfinite(d1))
+    sh = (8, 16, 24)
+    d_roll = emu.process_box(np.roll(box, sh, axis=(1, 2, 3)), Z, OM, show_progress=False)
+    _close(d_roll, np.roll(d1, sh, axis=(1, 2, 3)), 1e-6, 1e-5, "translation equivariance")
+    cfg2 = J.SubboxConfig(size=(128,) * 3, ndiv=(2, 2, 2))
+    emu2 = J.create_emulator(load_params=False, processor_config=cfg2, compute_vel=False)
+    emu2.processor.params = p
+    d2 = emu2.process_box(box, Z, OM, show_progress=False)
+    _close(d2, d1, 1e-6, 1e-5, "ndiv independence")
+
+
+def test_velocity_scales_with_vel_fac_full_width():
+    """velocity proportional to vel_fac, displacement independent of it
+    (tests/test_style_nbody_emulator_vel_core.py:152-190), production width, one 224^3 -> 128^3 sub-box."""
+    m = J.StyleNBodyEmulatorVelCore()
+    p = m.init(7)
+    x = np.random.default_rng(1).standard_normal((1, 3, 224, 224, 224)).astype(np.float32)
+    Dz = np.array([0.77], np.float32)
+    d1, v1 = m.apply(p, x, np.array([0.3]), Dz, np.array([10.0]))
+    d2, v2 = m.apply(p, x, np.array([0.3]), Dz, np.array([20.0]))
+    assert d1.shape == (1, 3, 128, 128, 128)
+    assert np.array_equal(d1, d2)
+    np.testing.assert_allclose(v2, 2 * v1, rtol=1e-5, atol=1e-6)
+    d0, v0 = m.apply(p, x, np.array([0.3]), Dz, np.array([0.0]))
+    assert np.all(v0 == 0)
+
+
+def test_resident_tensors_and_region_path():
+    """CUDA tensors stay resident (no PCIe copies); the brick/region path used for multi-GPU sharding
+    (world_size 1: halos are local periodic wraps) equals plain process_box."""
+    import torch
+    from jax_nbody_emulator_with_dj_amd import sharding
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
+    p = _synthetic(9, 8)
+    size, ndiv = (128, 64, 64), (2, 1, 1)
+    box = torch.randn((3,) + size, device="cuda")
+    cfg = J.SubboxConfig(size=size, ndiv=ndiv)
+    proc = J.SubboxProcessor(m, p, cfg)
+    dis, vel = proc.process_box(box, Z, OM, show_progress=False)
+    assert dis.is_cuda and dis.shape == box.shape
+    eng = get_engine(m, 0)
+    Dz, vf = float(J.growth_factor(Z, OM)), float(J.vel_norm(Z, OM))
+    sb = sharding.ShardedBox(eng, size, ndiv, rank=0, world_size=1)
+    d2, v2 = torch.zeros_like(box), torch.zeros_like(box)
+    sb.process(box, Dz, vf, d2, v2)
+    torch.cuda.synchronize()
+    eng.synchronize()
+    assert torch.equal(dis, d2) and torch.equal(vel, v2)
+
+
+def test_internal_tile_merging_is_exact():
+    """nbe_plan_tiles: merging sub-boxes into larger internal tiles (crop % 8 == 0) must not change the
+    result beyond rounding, and must be refused when crop % 8 != 0."""
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
+    p = _synthetic(13, 8)
+    eng = get_engine(m, 0)
+    assert eng.plan_tiles((512,) * 3, (4,) * 3) == (2, 2, 2)
+    assert eng.plan_tiles((32, 16, 16), (4, 2, 2)) == (1, 1, 1)
+    assert eng.plan_tiles((36, 16, 16), (3, 2, 2)) == (3, 2, 2)           # crop 12: lattice phase would change
+    size, ndiv = (32, 16, 16), (4, 2, 2)
+    box = np.random.default_rng(2).standard_normal((3,) + size).astype(np.float32)
+    proc = J.SubboxProcessor(m, p, J.SubboxConfig(size=size, ndiv=ndiv))
+    try:
+        eng.set_max_tile(0)
+        d0, v0 = proc.process_box(box, Z, OM, show_progress=False)
+        eng.set_max_tile(256)
+        d1, v1 = proc.process_box(box, Z, OM, show_progress=False)
+    finally:
+        eng.set_max_tile(256)
+    _close(d1, d0, 1e-6, 1e-5, "merged tiles disp")
+    _close(v1, v0, 1e-6, 1e-5, "merged tiles vel")
+
+
+def test_unsupported_shapes_raise():
+    m = J.StyleNBodyEmulatorCore(mid_chan=8)
+    p = _synthetic(1, 8)
+    with pytest.raises(Exception, match="multiple of 8|receptive field"):
+        m.apply(p, np.zeros((1, 3, 100, 104, 104), np.float32), np.array([0.3]), np.array([1.0]))
+    with pytest.raises(Exception, match="channels"):
+        m.apply(p, np.zeros((1, 2, 104, 104, 104), np.float32), np.array([0.3]), np.array([1.0]))

@@ -1,0 +1,98 @@
+"""CPU, multi-process: the N > 1 path's halo exchange and brick bookkeeping with the gloo backend
+(world_size 2 and 4 on the CPU); the same code runs over RCCL on GPUs."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from jax_nbody_emulator_with_dj_amd import sharding as S
+
+
+def test_rank_grid_and_bricks():
+    assert S.rank_grid(1, (4, 4, 4)) == (1, 1, 1)
+    assert S.rank_grid(2, (4, 4, 4)) == (2, 1, 1)
+    assert S.rank_grid(4, (4, 4, 4)) == (2, 2, 1)
+    assert S.rank_grid(8, (4, 4, 4)) == (2, 2, 2)
+    assert S.rank_grid(8, (8, 8, 8)) == (2, 2, 2)
+    assert S.rank_grid(16, (4, 4, 4)) == (4, 2, 2)
+    assert S.rank_grid(2, (1, 4, 4)) == (1, 2, 1)
+    with pytest.raises(ValueError):
+        S.rank_grid(8, (1, 1, 4))
+    grid = (2, 2, 2)
+    seen = set()
+    cover = np.zeros((512,) * 3, np.int8)
+    for r in range(8):
+        c = S.rank_coords(r, grid)
+        assert S.coords_rank(c, grid) == r
+        o, b = S.brick_extent(c, grid, (512,) * 3)
+        assert b == (256, 256, 256)
+        cover[o[0]:o[0] + b[0], o[1]:o[1] + b[1], o[2]:o[2] + b[2]] += 1
+        seen.add(c)
+    assert len(seen) == 8 and np.all(cover == 1)
+    assert S.coords_rank((-1, 2, 0), grid) == S.coords_rank((1, 0, 0), grid)     # periodic
+    assert S.local_ndiv((4, 4, 4), grid) == (2, 2, 2)
+
+
+def test_split_interior():
+    # C4: 2x2x2 sub-boxes of 128 per 256-brick -> every crop needs the halo
+    i, b = S.split_interior((2, 2, 2), (256, 256, 256))
+    assert i == [] and len(b) == 8
+    # C5: 4x4x4 sub-boxes of 128 per 512-brick -> the inner 2x2x2 are independent of the neighbours
+    i, b = S.split_interior((4, 4, 4), (512, 512, 512))
+    assert len(i) == 8 and len(b) == 56 and sorted(i + b) == list(range(64))
+    assert i[0] == (1 * 4 + 1) * 4 + 1
+    # small crops (crop < pad): an "inner" index is not enough, the haloed crop must fit
+    i, b = S.split_interior((4, 4, 4), (128, 128, 128))
+    assert i == []
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ndiv, size, pad, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grid = S.rank_grid(world, ndiv)
+        coords = S.rank_coords(rank, grid)
+        origin, bshape = S.brick_extent(coords, grid, size)
+        full = torch.from_numpy(np.random.default_rng(123).standard_normal((3,) + size).astype(np.float32))
+        brick = full[:, origin[0]:origin[0] + bshape[0], origin[1]:origin[1] + bshape[1],
+                     origin[2]:origin[2] + bshape[2]].contiguous()
+        H = S.exchange_halo(brick, grid, coords, pad)
+        # reference: periodic gather of the haloed brick from the global box (subbox.py:90-95 index rule)
+        idx = [np.arange(o - pad, o + b + pad) % s for o, b, s in zip(origin, bshape, size)]
+        want = full[:, idx[0][:, None, None], idx[1][None, :, None], idx[2][None, None, :]]
+        q.put((rank, bool(torch.equal(H, want)), tuple(H.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ndiv,size,pad", [(2, (2, 2, 2), (16, 12, 10), 4),
+                                                 (2, (1, 2, 1), (10, 16, 12), 5),
+                                                 (4, (4, 4, 4), (24, 16, 12), 6),
+                                                 (4, (4, 1, 1), (32, 10, 8), 8)])
+def test_halo_exchange_matches_periodic_gather(world, ndiv, size, pad):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ndiv, size, pad, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
