@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: dense f16/bf16 MFMA
 Z, OM = 0.5, 0.3
 
 
@@ -60,6 +61,8 @@ def main():
     ap.add_argument("--max-tile", type=int, default=256,
                     help="internal tile edge: sub-boxes are merged into tiles up to this size when that is exact "
                          "(crop %% 8 == 0); 0 = run the caller's 64 sub-boxes of 224^3 one by one")
+    ap.add_argument("--precision", default=os.environ.get("NBE_PRECISION", "f32"), choices=["f32", "f16x3"],
+                    help="f32: strict float32 MFMA; f16x3: float32-equivalent split-f16 MFMA (3 MFMAs per product)")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +89,7 @@ def main():
     vel = not args.no_vel
     model = (StyleNBodyEmulatorVelCore if vel else StyleNBodyEmulatorCore)()
     params = model.init(1234)
-    eng = Engine(device=local_rank, compute_vel=vel)
+    eng = Engine(device=local_rank, compute_vel=vel, precision=args.precision)
     eng.load_params(params, premodulated=False)
     Dz = float(np.float32(cosmology.growth_factor(Z, OM)))
     vf = float(np.float32(cosmology.vel_norm(Z, OM)))
@@ -142,7 +145,9 @@ def main():
             "metric": "voxels/sec (disp+vel) on 512^3 box, ndiv=4" if vel else "voxels/sec (disp only)",
             "value": vox / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32 via f16x3 split MFMA (f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "process_box %d^3 ndiv=(%d,%d,%d) compute_vel=%s StyleNBodyEmulator%sCore, "
                                    "synthetic seeded weights, box resident in HBM" % (N, *ndiv, vel, "Vel" if vel else ""),
                        "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,),
@@ -156,8 +161,11 @@ def main():
             dom = max(prof, key=lambda e: e["ms"])
             tot_ms = sum(e["ms"] for e in prof)
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            # f16x3 issues three f16 MFMAs per float32 product: price algorithmic FLOPs against 1/3 of the
+            # dense f16 MFMA peak (2.5 PFLOP/s)
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                                "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
                                "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
             out["kernels"] = [{"kernel": e["kernel"], "ms": round(e["ms"], 3), "launches": e["launches"],

@@ -57,6 +57,14 @@ int nbe_synchronize(nbe_ctx* ctx);
  * (nbody_emulator.py:324-339). */
 int nbe_set_arch(nbe_ctx* ctx, int in_chan, int out_chan, int mid_chan, float eps, int compute_vel);
 
+/* Arithmetic of the convolutions (call before loading weights).  The reference selects it through the dtype
+ * of x (SubboxConfig.dtype, style_layers_vel.py:103-105); its float32 runs on TF32-class tensor cores.
+ *   NBE_PREC_F32    strict float32 MFMA (default)
+ *   NBE_PREC_F16X3  float32-equivalent: operands split into two f16 numbers, three f16 MFMAs per product,
+ *                   float32 accumulation (22-bit operands; measured whole-network error equal to float32's) */
+enum { NBE_PREC_F32 = 0, NBE_PREC_F16X3 = 1 };
+int nbe_set_precision(nbe_ctx* ctx, int precision);
+
 /* replaces model.apply's `params` argument for the Style* cores (README.md:155; subbox.py:224-233) */
 int nbe_load_style_weights(nbe_ctx* ctx, const nbe_layer_desc* layers, int nlayers);
 /* replaces `params` of the premodulated cores: output of modulate_emulator_parameters[_vel]

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnbe.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("nbe_kernels.hip", "nbe_engine.cpp")
+SOURCES = ("nbe_kernels.hip", "nbe_kernels_h3.hip", "nbe_engine.cpp")
 
 
 class NBEError(RuntimeError):
@@ -54,6 +54,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "nbe_plan_tiles": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "nbe_set_max_tile": (C.c_int, [C.c_void_p, C.c_int]),
+    "nbe_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_growth_factor": (C.c_double, [C.c_double, C.c_double]),
     "nbe_vel_norm": (C.c_double, [C.c_double, C.c_double]),
     "nbe_test_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -75,7 +76,7 @@ _lib = None
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into libnbe.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "nbe_kernels.h"), os.path.join(_HERE, "..", "include", "nbe.h")]
+    deps = srcs + [os.path.join(CSRC, "nbe_kernels.h"), os.path.join(CSRC, "nbe_kernels_internal.h"), os.path.join(_HERE, "..", "include", "nbe.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
             return LIB_PATH

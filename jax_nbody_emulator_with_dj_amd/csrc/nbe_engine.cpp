@@ -93,6 +93,7 @@ struct nbe_ctx {
     int64_t ws_bytes = 0;
     bool dry = false;
     int max_tile = 256;                           // internal tile edge (output voxels); 0 = caller's grid as given
+    int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     // device-resident boxes of process_box
     float* box_in = nullptr; int64_t box_in_bytes = 0;
     char* box_out = nullptr; int64_t box_out_bytes = 0;
@@ -195,7 +196,10 @@ static void prof_collect(nbe_ctx* c) {
 static std::string conv_name(const PackedW& pw, bool vel, bool has_dx) {
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
     char b[96];
-    snprintf(b, sizeof b, "conv_mfma<%s,%s,%s,ni%d>", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx", pw.ni);
+    if (pw.prec == PREC_F16X3)
+        snprintf(b, sizeof b, "conv_h3<%s,%s,%s>", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx");
+    else
+        snprintf(b, sizeof b, "conv_mfma<%s,%s,%s,ni%d>", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx", pw.ni);
     return b;
 }
 
@@ -385,9 +389,9 @@ static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int 
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
     // core :132-134: x = x * (Dz / 6)
-    launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f, c->stream);
+    launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f, c->prec, c->stream);
     if (network(c, tin, &y)) return 1;
-    launch_head(y.p, tin.p, 48, c->out_chan, Dz, vel_fac, c->vel, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, c->stream);
+    launch_head(y.p, tin.p, 48, c->out_chan, Dz, vel_fac, c->vel, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, c->prec, c->stream);
     return 0;
 }
 
@@ -451,9 +455,10 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
         const size_t nw = (size_t)d.cout * d.cin * d.k * d.k * d.k;
         PackedW& pw = L.pw;
         pw.mode = L.kind == 0 ? MODE_FLAT3 : (L.kind == 2 ? MODE_DOWN : MODE_FLAT1);
-        pw.ni = d.cout > 32 ? 2 : 1;
+        pw.prec = c->prec;
+        pw.ni = (c->prec == PREC_F16X3 || d.cout > 32) ? 2 : 1;
         pw.cin = d.cin; pw.cout = d.cout;
-        pw.cin_pad = roundup(d.cin, mode_ck(pw.mode));
+        pw.cin_pad = roundup(d.cin, prec_ck(c->prec, pw.mode));
         pw.ctiles = (d.cout + 32 * pw.ni - 1) / (32 * pw.ni);
         pw.nsets = L.kind == 3 ? 8 : 1;
         pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad;
@@ -648,6 +653,15 @@ int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int
     return 0;
 }
 
+int nbe_set_precision(nbe_ctx* c, int prec) {
+    if (!c) return fail("null context");
+    if (prec != PREC_F32 && prec != PREC_F16X3) return fail("precision must be NBE_PREC_F32 (0) or NBE_PREC_F16X3 (1)");
+    if (c->have_weights && prec != c->prec)
+        return fail("nbe_set_precision must be called before the weights are loaded (they are packed per precision)");
+    c->prec = prec;
+    return 0;
+}
+
 int nbe_set_max_tile(nbe_ctx* c, int max_tile) {
     if (!c) return fail("null context");
     if (max_tile < 0) return fail("max_tile must be >= 0 (0 = keep the caller's sub-box grid)");
@@ -796,8 +810,9 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         L.cout = cout; L.cin = cin; L.k = k; L.kind = kind;
         PackedW& pw = L.pw;
         pw.mode = kind == 0 ? MODE_FLAT3 : (kind == 2 ? MODE_DOWN : MODE_FLAT1);
-        pw.ni = cout > 32 ? 2 : 1; pw.cin = cin; pw.cout = cout;
-        pw.cin_pad = roundup(cin, mode_ck(pw.mode));
+        pw.prec = c->prec;
+        pw.ni = (c->prec == PREC_F16X3 || cout > 32) ? 2 : 1; pw.cin = cin; pw.cout = cout;
+        pw.cin_pad = roundup(cin, prec_ck(c->prec, pw.mode));
         pw.ctiles = (cout + 32 * pw.ni - 1) / (32 * pw.ni);
         pw.nsets = kind == 3 ? 8 : 1;
         pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad;
@@ -825,14 +840,14 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         pin.x = (float*)ws; pin.dx = (float*)(ws + bi);
         pout.x = (float*)(ws + 2 * bi); pout.dx = (float*)(ws + 2 * bi + bo);
         pres.x = (float*)(ws + 2 * bi + 2 * bo); pres.dx = (float*)(ws + 2 * bi + 3 * bo);
-        launch_to_planes(dxin, cin, pin, false, 1.0f, c->stream);
-        if (has_dx) launch_to_planes(ddx, cin, pin, true, 1.0f, c->stream);
+        launch_to_planes(dxin, cin, pin, false, 1.0f, c->prec, c->stream);
+        if (has_dx) launch_to_planes(ddx, cin, pin, true, 1.0f, c->prec, c->stream);
         if (flags & F_RES) {
             if (!res) { rc = fail("residual flag set but res is NULL"); break; }
             TCHK(hipMemcpyAsync(dout, res, nout * 4, hipMemcpyHostToDevice, c->stream));
-            launch_to_planes(dout, cout, pres, false, 1.0f, c->stream);
+            launch_to_planes(dout, cout, pres, false, 1.0f, c->prec, c->stream);
             if (vel && dres) { TCHK(hipStreamSynchronize(c->stream)); TCHK(hipMemcpyAsync(dout, dres, nout * 4, hipMemcpyHostToDevice, c->stream));
-                               launch_to_planes(dout, cout, pres, true, 1.0f, c->stream); }
+                               launch_to_planes(dout, cout, pres, true, 1.0f, c->prec, c->stream); }
             TCHK(hipStreamSynchronize(c->stream));
         }
         ConvLaunch cl; cl.in = pin; cl.out = pout; cl.res = pres; cl.flags = flags;
@@ -845,11 +860,11 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
                 run_conv(c, L, u, has_dx);
             }
         }
-        launch_from_planes(pout, false, cout, dout, c->stream);
+        launch_from_planes(pout, false, cout, dout, c->prec, c->stream);
         TCHK(hipStreamSynchronize(c->stream));
         TCHK(hipMemcpy(y, dout, nout * 4, hipMemcpyDeviceToHost));
         if (vel) {
-            launch_from_planes(pout, true, cout, dout, c->stream);
+            launch_from_planes(pout, true, cout, dout, c->prec, c->stream);
             TCHK(hipStreamSynchronize(c->stream));
             TCHK(hipMemcpy(dy, dout, nout * 4, hipMemcpyDeviceToHost));
         }

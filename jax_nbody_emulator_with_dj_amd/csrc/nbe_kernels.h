@@ -18,6 +18,17 @@ struct Planes {
     int64_t vox() const { return (int64_t)D * H * W; }
 };
 
+// Arithmetic of the convolutions:
+//   PREC_F32    strict float32: v_mfma_f32_32x32x2_f32 on float4 planes (C/4 planes of 4 x f32 per voxel)
+//   PREC_F16X3  float32-equivalent split: every operand x is stored as two f16 numbers
+//               hi = f16(x), lo = f16((x - hi) * 2^11); a product a*b is evaluated as
+//               a_hi*b_hi + 2^-11 * (a_hi*b_lo + a_lo*b_hi) on v_mfma_f32_32x32x16_f16 with float32
+//               accumulation (22 significant bits per operand; the dropped lo*lo term is 2^-22 relative).
+//               Planes hold 8 x f16 per voxel: plane 2g = hi, 2g+1 = lo of channels 8g..8g+7 -- the same
+//               bytes and plane count as PREC_F32, so workspace planning is identical.
+enum Precision { PREC_F32 = 0, PREC_F16X3 = 1 };
+constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
+
 enum ConvMode { MODE_FLAT3 = 0, MODE_FLAT1 = 1, MODE_DOWN = 2 };
 enum ConvFlags { F_ACT = 1, F_RES = 2 };
 
@@ -26,13 +37,15 @@ constexpr int TILE_VOX = 256;                 // voxels per workgroup tile
 inline constexpr int mode_taps(int mode) { return mode == MODE_FLAT3 ? 3 : 1; }
 inline constexpr int mode_nseg(int mode) { return mode == MODE_FLAT3 ? 9 : (mode == MODE_DOWN ? 8 : 1); }
 inline constexpr int mode_ck(int mode) { return mode == MODE_FLAT3 ? 8 : 16; }
+inline constexpr int prec_ck(int prec, int mode) { return prec == PREC_F16X3 ? 16 : mode_ck(mode); }
 
 // One packed weight set (see pack_index in nbe_kernels.hip for the layout).
 struct PackedW {
     float* w = nullptr;      // [ct][stage = chunk*nseg + seg][tap][CK/4][COUT_T][4]
     float* dw = nullptr;
     float* bias = nullptr;   // padded to ct*COUT_T
-    int mode = 0, ni = 2;    // COUT_T = 32*ni
+    int prec = PREC_F32;
+    int mode = 0, ni = 2;    // COUT_T = 32*ni (PREC_F16X3: always 64)
     int cin = 0, cout = 0;   // logical channels
     int cin_pad = 0;         // multiple of CK
     int ctiles = 0;          // cout tiles
@@ -45,7 +58,7 @@ struct ConvLaunch {
     int64_t in_off = 0;      // FLAT modes: flat input offset of output position q (crop)
     int Dv = 0, Hv = 0, Wv = 0;   // FLAT: valid output extents along z,y,x in q coordinates; DOWN: output dims
     Planes out;              // output planes; written planes are out_g0 + cout group
-    int out_g0 = 0;
+    int out_g0 = 0;          // first output PLANE (concat offset)
     int osz = 1, oz = 0, oy = 0, ox = 0;   // output voxel = (z*osz+oz, y*osz+oy, x*osz+ox) in out geometry
     Planes res;              // residual (same geometry as out), used when flags & F_RES
     int flags = 0;
@@ -65,16 +78,16 @@ void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const Packed
 // data movement --------------------------------------------------------------
 // periodic crop of a (C, Db, Hb, Wb) float box into input planes, scaled by `scale`
 void launch_gather(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                   const Planes& dst, float scale, hipStream_t s);
+                   const Planes& dst, float scale, int prec, hipStream_t s);
 // NCDHW (C,D,H,W) dense -> planes (+scale), and back (debug / apply path)
-void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, hipStream_t s);
-void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, hipStream_t s);
+void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, int prec, hipStream_t s);
+void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, int prec, hipStream_t s);
 // centre crop by c voxels per side into planes [g0, g0+src.G) of dst
 void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s);
 // head: disp = (y + x0)*6 ; vel = dy*(vf*6) + x0*(vf*6/Dz); x0 = input planes cropped by `c0`;
 // written to a (C, Db, Hb, Wb) box at origin (a0,a1,a2); out_dtype 0 = f32, 1 = f16
 void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                 hipStream_t s);
+                 int prec, hipStream_t s);
 
 }  // namespace nbe

@@ -19,33 +19,14 @@
 // with 4 consecutive output channels of one voxel = one float4 store into the output plane.
 // The tangent (velocity) path shares every staged operand: y += W.X, dy += dW.X + W.dX.
 
-#include "nbe_kernels.h"
+#include "nbe_kernels_internal.h"
 
 namespace nbe {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define LDS_AS __attribute__((address_space(3)))
-#define GLB_AS __attribute__((address_space(1)))
+#define LDS_AS NBE_LDS_AS
+#define GLB_AS NBE_GLB_AS
 
 extern __shared__ __attribute__((aligned(16))) f32x4 lds_dyn[];
-
-struct ConvKArgs {
-    const float* x; const float* dx; long in_pstride;
-    int D, H, W; long P; long in_off;
-    int Dv, Hv, Wv; long Q;
-    float* y; float* dy; long out_pstride; int out_g0;
-    int Ho, Wo; int osz, oz, oy, ox;
-    const float* r; const float* dr; long res_pstride;
-    const float* bias; const float* w; const float* dw;
-    int nchunk; int cout_groups; int flags; int ntiles;
-};
-
-__device__ __forceinline__ void dma16(const float* src, f32x4* dst_wave_base) {
-    // 64 lanes x 16 B: LDS destination = wave-uniform base + lane*16 (hardware rule), source per lane.
-    __builtin_amdgcn_global_load_lds((const GLB_AS void*)src, (LDS_AS void*)dst_wave_base, 16, 0, 0);
-}
 
 template <int MODE, bool VEL, bool HAS_DX, int NI>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
@@ -68,14 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run
-    // of tiles so that neighbouring tiles (which share input rows) hit the same L2.  Bijective form.
-    int tile;
-    {
-        const int nt = a.ntiles, b = blockIdx.x;
-        const int qd = nt >> 3, rm = nt & 7, xcd = b & 7;
-        tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
-    }
+    const int tile = xcd_tile(blockIdx.x, a.ntiles);
     const int ct = blockIdx.y;
     const long q0 = (long)tile * TILE_VOX;
     const int nchunk = a.nchunk;
@@ -258,10 +232,11 @@ void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, 
     ka.bias = pw.bias;
     ka.w = pw.w + (size_t)L.set * pw.floats;
     ka.dw = pw.dw ? pw.dw + (size_t)L.set * pw.floats : nullptr;
-    ka.nchunk = pw.cin_pad / mode_ck(pw.mode);
-    ka.cout_groups = (pw.cout + 3) / 4;
+    ka.nchunk = pw.cin_pad / prec_ck(pw.prec, pw.mode);
+    ka.cout_groups = pw.prec == PREC_F16X3 ? (pw.cout + 7) / 8 : (pw.cout + 3) / 4;
     ka.flags = L.flags;
     ka.ntiles = (int)((ka.Q + TILE_VOX - 1) / TILE_VOX);
+    if (pw.prec == PREC_F16X3) { launch_conv_h3(pw, ka, vel, has_dx, s); return; }
     const int ct = pw.ctiles;
 #define NBE_DISPATCH(MODE)                                                                   \
     if (vel) {                                                                               \
@@ -373,6 +348,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 }
 
 void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s) {
+    if (pw.prec == PREC_F16X3) { launch_pack_h3(w_oidhw, cout, cin, kind, pw, dst, s); return; }
     const long total = pw.floats * pw.nsets;
     const int nchunk = pw.cin_pad / mode_ck(pw.mode);
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
@@ -406,13 +382,15 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ b
 }
 
 void launch_gather(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                   const Planes& dst, float scale, hipStream_t s) {
+                   const Planes& dst, float scale, int prec, hipStream_t s) {
+    if (prec == PREC_F16X3) { launch_gather_h8(box, C, Db, Hb, Wb, a0, a1, a2, dst.x, dst, scale, s); return; }
     const long V = dst.vox();
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, box, C, Db, Hb, Wb,
                        a0, a1, a2, dst.x, dst.pstride, dst.G, dst.D, dst.H, dst.W, scale);
 }
 
-void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, hipStream_t s) {
+void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, int prec, hipStream_t s) {
+    if (prec == PREC_F16X3) { launch_gather_h8(src, C, dst.D, dst.H, dst.W, 0, 0, 0, tangent ? dst.dx : dst.x, dst, scale, s); return; }
     // a dense (C,D,H,W) array is a "box" of the same size gathered at origin 0
     const long V = dst.vox();
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, src, C, dst.D, dst.H,
@@ -431,7 +409,8 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const float* __restric
     }
 }
 
-void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, hipStream_t s) {
+void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, int prec, hipStream_t s) {
+    if (prec == PREC_F16X3) { launch_from_planes_h8(tangent ? src.dx : src.x, src, C, dst, s); return; }
     const long V = src.vox();
     hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s,
                        tangent ? src.dx : src.x, src.pstride, V, C, dst);
@@ -493,7 +472,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, 
 
 void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                 hipStream_t s) {
+                 int prec, hipStream_t s) {
+    if (prec == PREC_F16X3) { launch_head_h8(y, xin, c0, C, Dz, vel_fac, vel, disp, velo, out_dtype, Db, Hb, Wb, a0, a1, a2, s); return; }
     const long V = y.vox();
     const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
     dim3 grid((unsigned)((V + 255) / 256)), block(256);

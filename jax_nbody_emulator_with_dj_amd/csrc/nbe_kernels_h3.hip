@@ -1,0 +1,386 @@
+// gfx950 kernels of the float32-equivalent split-precision path (PREC_F16X3).
+//
+// Same algorithm, schedule and tiling as nbe_kernels.hip (flat-shift implicit GEMM, LDS staging by
+// global->LDS DMA, XCD-aware tiles); what changes is the arithmetic: every operand is a pair of f16 numbers
+// (hi = f16(x), lo = f16((x - hi) * 2^11)) and one float32 product becomes three f16 MFMAs with float32
+// accumulation,   a*b  ~=  a_hi*b_hi  +  2^-11 * (a_hi*b_lo + a_lo*b_hi),
+// i.e. 22 significant bits per operand.  v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32 MFMA, so the
+// 3-term split is ~5.3x the strict-float32 matrix rate.  Measured accuracy: tests/test_gpu_h3.py.
+//
+// Storage: plane 2g holds hi, plane 2g+1 holds lo of channels 8g..8g+7 (8 x f16 = 16 B per voxel): one
+// 16-byte unit is exactly the A/B operand of one lane for one MFMA (k = 8*(lane>>5) + j).
+
+#include "nbe_kernels_internal.h"
+
+namespace nbe {
+
+extern __shared__ __attribute__((aligned(16))) f32x4 lds_h3[];
+
+__device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)v[e];
+        lo[e] = (_Float16)((v[e] - (float)hi[e]) * H3_SCALE);
+    }
+}
+__device__ __forceinline__ f32x4 join4(const half4 hi, const half4 lo) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)hi[e] + (float)lo[e] * H3_INV;
+    return v;
+}
+
+// Workgroup: 512 threads = 8 waves; tile = 64 output channels x 256 flat positions.
+// wave w: it = w & 1 (32 couts), jq = w >> 1 (64 positions = 2 MFMA column tiles).
+template <int MODE, bool VEL, bool HAS_DX>
+__global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
+    constexpr int TAPS = mode_taps(MODE);
+    constexpr int XV = (MODE == MODE_FLAT3) ? 320 : 256;
+    constexpr int WP = TAPS * 4 * 64;                // 16-byte units of one weight stage (16 channels)
+    constexpr int XP = 4 * XV;                       // 16-byte units of one activation stage
+    constexpr bool DX = VEL && HAS_DX;
+    constexpr int OFF_W = 0, OFF_DW = WP, OFF_X = OFF_DW + (VEL ? WP : 0), OFF_DXX = OFF_X + XP;
+    constexpr int BUF = OFF_DXX + (DX ? XP : 0);
+    constexpr int NIW = WP / 64, NIX = XP / 64;
+    constexpr int NW_TOT = NIW * (VEL ? 2 : 1);
+    constexpr int NINSTR = NW_TOT + NIX * (DX ? 2 : 1);
+
+    f32x4* lds = lds_h3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int it = wave & 1, jq = wave >> 1;
+
+    const int tile = xcd_tile(blockIdx.x, a.ntiles);
+    const int ct = blockIdx.y;
+    const long q0 = (long)tile * TILE_VOX;
+    const int nstage = mode_nseg(MODE) * a.nchunk;
+    const long HW = (long)a.H * a.W;
+
+    int* inbase = (int*)(lds + 2 * BUF);
+    if (MODE == MODE_DOWN) {
+        if (tid < TILE_VOX) {
+            long o = q0 + tid;
+            if (o > a.Q - 1) o = a.Q - 1;
+            const int hw = a.Hv * a.Wv;
+            const int zo = (int)(o / hw), rem = (int)(o - (long)zo * hw);
+            const int yo = rem / a.Wv, xo = rem - yo * a.Wv;
+            inbase[tid] = (int)((2L * zo * a.H + 2 * yo) * a.W + 2 * xo);
+        }
+        __syncthreads();
+    }
+
+    auto issue = [&](int s, int b) {
+        const int chunk = s / mode_nseg(MODE), seg = s - chunk * mode_nseg(MODE);
+        long segoff;
+        if (MODE == MODE_FLAT3) segoff = (seg / 3) * HW + (seg % 3) * a.W;
+        else if (MODE == MODE_DOWN) segoff = (seg >> 2) * HW + ((seg >> 1) & 1) * a.W + (seg & 1);
+        else segoff = 0;
+        const long wbase = ((long)(ct * nstage + s) * WP) * 4;
+        f32x4* buf = lds + b * BUF;
+#pragma unroll
+        for (int t = 0; t < (NINSTR + 7) / 8; ++t) {
+            const int n = wave + 8 * t;              // wave-uniform instruction slot
+            if (n < NIW) {
+                dma16(a.w + wbase + (long)(n * 64 + lane) * 4, buf + OFF_W + n * 64);
+            } else if (VEL && n < NW_TOT) {
+                const int m = n - NIW;
+                dma16(a.dw + wbase + (long)(m * 64 + lane) * 4, buf + OFF_DW + m * 64);
+            } else if (n < NINSTR) {
+                const bool tang = DX && n >= NW_TOT + NIX;
+                const int m = n - NW_TOT - (tang ? NIX : 0);
+                const int pl = (m * 64) / XV;        // plane inside the 16-channel chunk: 2*h + part
+                const int vl = (m * 64) % XV + lane;
+                long v;
+                if (MODE == MODE_DOWN) v = (long)inbase[vl] + segoff;
+                else {
+                    v = q0 + a.in_off + segoff + vl;
+                    if (v > a.P - 1) v = a.P - 1;
+                }
+                const long off = ((long)(chunk * 4 + pl) * a.in_pstride + v) * 4;
+                dma16((tang ? a.dx : a.x) + off, buf + (tang ? OFF_DXX : OFF_X) + m * 64);
+            }
+        }
+    };
+
+    // main / correction accumulators of y and dy: 2 column tiles each
+    f32x16 ym[2], yc[2], dm[2], dc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ym[jt][e] = 0.f; yc[jt][e] = 0.f; dm[jt][e] = 0.f; dc[jt][e] = 0.f; }
+
+    auto compute = [&](int b) {
+        const half8* buf = (const half8*)(lds + b * BUF);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int wo = (tap * 4 + 2 * lh) * 64 + 32 * it + li;
+            const half8 wh = buf[OFF_W + wo], wl = buf[OFF_W + wo + 64];
+            half8 dwh, dwl;
+            if (VEL) { dwh = buf[OFF_DW + wo]; dwl = buf[OFF_DW + wo + 64]; }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int xo = (2 * lh) * XV + jq * 64 + 32 * jt + li + (MODE == MODE_FLAT3 ? tap : 0);
+                const half8 xh = buf[OFF_X + xo], xl = buf[OFF_X + xo + XV];
+                ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
+                yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, yc[jt], 0, 0, 0);
+                yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, yc[jt], 0, 0, 0);
+                if (VEL) {
+                    dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xh, dm[jt], 0, 0, 0);
+                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xl, dc[jt], 0, 0, 0);
+                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwl, xh, dc[jt], 0, 0, 0);
+                }
+                if (DX) {
+                    const half8 dxh = buf[OFF_DXX + xo], dxl = buf[OFF_DXX + xo + XV];
+                    dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxh, dm[jt], 0, 0, 0);
+                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxl, dc[jt], 0, 0, 0);
+                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dxh, dc[jt], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    issue(0, 0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) issue(s + 1, (s + 1) & 1);
+        compute(s & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    const bool act = a.flags & F_ACT, res = a.flags & F_RES;
+    char* const yb = (char*)a.y;
+    char* const dyb = (char*)a.dy;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const long q = q0 + jq * 64 + 32 * jt + li;
+        bool valid = q < a.Q;
+        long o;
+        if (MODE == MODE_DOWN) {
+            o = q;
+        } else {
+            const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
+            const int yy = rem / a.W, xx = rem - yy * a.W;
+            valid = valid && xx < a.Wv && yy < a.Hv && z < a.Dv;
+            o = ((long)(z * a.osz + a.oz) * a.Ho + (yy * a.osz + a.oy)) * a.Wo + (xx * a.osz + a.ox);
+        }
+        if (!valid) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int unit = ct * 8 + 4 * it + k;                // 8-channel group of the output
+            if (unit >= a.cout_groups) continue;
+            const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * lh);
+            f32x4 v, dv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = ym[jt][4 * k + e] + yc[jt][4 * k + e] * H3_INV + bv[e];
+                dv[e] = dm[jt][4 * k + e] + dc[jt][4 * k + e] * H3_INV;
+            }
+            if (res) {
+                const long rb = ((long)(2 * unit) * a.res_pstride + o) * 16 + 8 * lh;
+                const long rl = rb + a.res_pstride * 16;
+                v += join4(*(const half4*)((const char*)a.r + rb), *(const half4*)((const char*)a.r + rl));
+                if (VEL) dv += join4(*(const half4*)((const char*)a.dr + rb), *(const half4*)((const char*)a.dr + rl));
+            }
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (VEL) dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                    v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                }
+            }
+            const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + o) * 16 + 8 * lh;
+            const long ol = ob + a.out_pstride * 16;
+            half4 hi, lo;
+            split4(v, hi, lo);
+            *(half4*)(yb + ob) = hi;
+            *(half4*)(yb + ol) = lo;
+            if (VEL) {
+                split4(dv, hi, lo);
+                *(half4*)(dyb + ob) = hi;
+                *(half4*)(dyb + ol) = lo;
+            }
+        }
+    }
+}
+
+template <int MODE, bool VEL, bool HAS_DX>
+static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
+    constexpr int TAPS = mode_taps(MODE);
+    constexpr int XV = (MODE == MODE_FLAT3) ? 320 : 256;
+    constexpr int WP = TAPS * 4 * 64, XP = 4 * XV;
+    constexpr int BUF = WP * (VEL ? 2 : 1) + XP * ((VEL && HAS_DX) ? 2 : 1);
+    constexpr size_t smem = (size_t)2 * BUF * 16 + TILE_VOX * sizeof(int);
+    auto kern = conv_h3_kernel<MODE, VEL, HAS_DX>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
+}
+
+void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
+    const int ct = pw.ctiles;
+#define NBE_DISPATCH_H3(MODE)                                                   \
+    if (vel) { if (has_dx) launch_h3_t<MODE, true, true>(ka, ct, s);            \
+               else launch_h3_t<MODE, true, false>(ka, ct, s); }                \
+    else launch_h3_t<MODE, false, false>(ka, ct, s);
+    if (pw.mode == MODE_FLAT3) { NBE_DISPATCH_H3(MODE_FLAT3) }
+    else if (pw.mode == MODE_FLAT1) { NBE_DISPATCH_H3(MODE_FLAT1) }
+    else { NBE_DISPATCH_H3(MODE_DOWN) }
+#undef NBE_DISPATCH_H3
+}
+
+// packed layout: [set][ct][stage = chunk*nseg + seg][tap][u = 2*h + part][co 64][j 8];
+// channel = chunk*16 + 8*h + j; part 0 = hi, 1 = lo * 2^11
+__global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ w, int cout, int cin, int kind,
+                                                      int mode, int nchunk, long halves_per_set, int nsets,
+                                                      _Float16* __restrict__ dst) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= halves_per_set * nsets) return;
+    const int TAPS = mode_taps(mode), nseg = mode_nseg(mode);
+    const int nstage = nseg * nchunk;
+    long r = idx;
+    const int j = (int)(r % 8); r /= 8;
+    const int co = (int)(r % 64); r /= 64;
+    const int u = (int)(r % 4); r /= 4;
+    const int tap = (int)(r % TAPS); r /= TAPS;
+    const int stage = (int)(r % nstage); r /= nstage;
+    const long per_set_ct = halves_per_set / ((long)nstage * TAPS * 4 * 64 * 8);
+    const int ct = (int)(r % per_set_ct); r /= per_set_ct;
+    const int set = (int)r;
+    const int chunk = stage / nseg, seg = stage - chunk * nseg;
+    const int h = u >> 1, part = u & 1;
+    const int ci = chunk * 16 + 8 * h + j;
+    const int oc = ct * 64 + co;
+    int k, kz, ky, kx;
+    if (kind == 0) { k = 3; kz = seg / 3; ky = seg % 3; kx = tap; }
+    else if (kind == 1) { k = 1; kz = ky = kx = 0; }
+    else if (kind == 2) { k = 2; kz = seg >> 2; ky = (seg >> 1) & 1; kx = seg & 1; }
+    else { k = 2; kz = 1 - ((set >> 2) & 1); ky = 1 - ((set >> 1) & 1); kx = 1 - (set & 1); }
+    float v = 0.f;
+    if (oc < cout && ci < cin) v = w[(((size_t)oc * cin + ci) * k + kz) * k * k + ky * k + kx];
+    const _Float16 hi = (_Float16)v;
+    dst[idx] = part == 0 ? hi : (_Float16)((v - (float)hi) * H3_SCALE);
+}
+
+void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s) {
+    const long halves = pw.floats * 2;
+    const long total = halves * pw.nsets;
+    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
+                       kind, pw.mode, pw.cin_pad / 16, halves, pw.nsets, (_Float16*)dst);
+}
+
+// ------------------------------------------------------------------------------------------------
+// data movement in the 8 x f16 hi/lo plane format
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_h8_kernel(const float* __restrict__ box, int C, int Db, int Hb, int Wb,
+                                                        int a0, int a1, int a2, float* __restrict__ dst, long pstride,
+                                                        int G, int D, int H, int W, float scale) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long V = (long)D * H * W;
+    if (v >= V) return;
+    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const int bz = ((a0 + z) % Db + Db) % Db, by = ((a1 + y) % Hb + Hb) % Hb, bx = ((a2 + x) % Wb + Wb) % Wb;
+    const long bo = ((long)bz * Hb + by) * Wb + bx;
+    const long bstride = (long)Db * Hb * Wb;
+    for (int g = 0; 2 * g < G; ++g) {
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * g + e;
+            const float f = c < C ? box[c * bstride + bo] * scale : 0.f;
+            hi[e] = (_Float16)f;
+            lo[e] = (_Float16)((f - (float)hi[e]) * H3_SCALE);
+        }
+        *(half8*)(dst + ((long)(2 * g) * pstride + v) * 4) = hi;
+        *(half8*)(dst + ((long)(2 * g + 1) * pstride + v) * 4) = lo;
+    }
+}
+
+void launch_gather_h8(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                      float* dst, const Planes& geom, float scale, hipStream_t s) {
+    const long V = geom.vox();
+    hipLaunchKernelGGL(gather_h8_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, box, C, Db, Hb, Wb,
+                       a0, a1, a2, dst, geom.pstride, geom.G, geom.D, geom.H, geom.W, scale);
+}
+
+__global__ __launch_bounds__(256) void from_planes_h8_kernel(const float* __restrict__ src, long pstride, long V, int C,
+                                                             float* __restrict__ dst) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    for (int g = 0; 8 * g < C; ++g) {
+        const half8 hi = *(const half8*)(src + ((long)(2 * g) * pstride + v) * 4);
+        const half8 lo = *(const half8*)(src + ((long)(2 * g + 1) * pstride + v) * 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (8 * g + e < C) dst[(long)(8 * g + e) * V + v] = (float)hi[e] + (float)lo[e] * H3_INV;
+    }
+}
+
+void launch_from_planes_h8(const float* src, const Planes& geom, int C, float* dst, hipStream_t s) {
+    const long V = geom.vox();
+    hipLaunchKernelGGL(from_planes_h8_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, src, geom.pstride, V, C, dst);
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                      long ypstride, int D, int H, int W,
+                                                      const float* __restrict__ xin, long xpstride, int XH, int XW,
+                                                      int c0, int C, float k_dy, float k_x0, OT* __restrict__ disp,
+                                                      OT* __restrict__ velo, int Db, int Hb, int Wb, int a0, int a1,
+                                                      int a2) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long V = (long)D * H * W;
+    if (v >= V) return;
+    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
+    const int yy = rem / W, x = rem - yy * W;
+    const long xv = ((long)(z + c0) * XH + (yy + c0)) * XW + (x + c0);
+    const long bo = ((long)(a0 + z) * Hb + (a1 + yy)) * Wb + (a2 + x);
+    const long bstride = (long)Db * Hb * Wb;
+    for (int g = 0; 8 * g < C; ++g) {
+        const half8 yh = *(const half8*)(y + ((long)(2 * g) * ypstride + v) * 4);
+        const half8 yl = *(const half8*)(y + ((long)(2 * g + 1) * ypstride + v) * 4);
+        const half8 xh = *(const half8*)(xin + ((long)(2 * g) * xpstride + xv) * 4);
+        const half8 xl = *(const half8*)(xin + ((long)(2 * g + 1) * xpstride + xv) * 4);
+        half8 dh, dl;
+        if (dy) { dh = *(const half8*)(dy + ((long)(2 * g) * ypstride + v) * 4);
+                  dl = *(const half8*)(dy + ((long)(2 * g + 1) * ypstride + v) * 4); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * g + e;
+            if (c < C) {
+                const float yv = (float)yh[e] + (float)yl[e] * H3_INV;
+                const float x0 = (float)xh[e] + (float)xl[e] * H3_INV;
+                disp[c * bstride + bo] = (OT)((yv + x0) * 6.0f);
+                if (dy) {
+                    const float dv = (float)dh[e] + (float)dl[e] * H3_INV;
+                    velo[c * bstride + bo] = (OT)(dv * k_dy + x0 * k_x0);
+                }
+            }
+        }
+    }
+}
+
+void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+                    void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                    hipStream_t s) {
+    const long V = y.vox();
+    const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
+    dim3 grid((unsigned)((V + 255) / 256)), block(256);
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(head_h8_kernel<float>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D, y.H,
+                           y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (float*)disp, (float*)velo,
+                           Db, Hb, Wb, a0, a1, a2);
+    else
+        hipLaunchKernelGGL(head_h8_kernel<_Float16>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D,
+                           y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (_Float16*)disp,
+                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2);
+}
+
+}  // namespace nbe

@@ -1,0 +1,49 @@
+// Shared between nbe_kernels.hip (float32 path, data movement) and nbe_kernels_h3.hip (f16x3 path).
+#pragma once
+#include "nbe_kernels.h"
+
+namespace nbe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+#define NBE_LDS_AS __attribute__((address_space(3)))
+#define NBE_GLB_AS __attribute__((address_space(1)))
+
+// kernel arguments of every convolution variant (POD, passed by value)
+struct ConvKArgs {
+    const float* x; const float* dx; long in_pstride;
+    int D, H, W; long P; long in_off;
+    int Dv, Hv, Wv; long Q;
+    float* y; float* dy; long out_pstride; int out_g0;
+    int Ho, Wo; int osz, oz, oy, ox;
+    const float* r; const float* dr; long res_pstride;
+    const float* bias; const float* w; const float* dw;
+    int nchunk; int cout_groups; int flags; int ntiles;
+};
+
+__device__ __forceinline__ void dma16(const float* src, f32x4* dst_wave_base) {
+    // 64 lanes x 16 B: LDS destination = wave-uniform base + lane*16 (hardware rule), source per lane.
+    __builtin_amdgcn_global_load_lds((const NBE_GLB_AS void*)src, (NBE_LDS_AS void*)dst_wave_base, 16, 0, 0);
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run
+// of tiles so that neighbouring tiles (which share input rows) hit the same L2.  Bijective form.
+__device__ __forceinline__ int xcd_tile(int b, int nt) {
+    const int qd = nt >> 3, rm = nt & 7, xcd = b & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (b >> 3);
+}
+
+// f16x3 path (nbe_kernels_h3.hip)
+void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s);
+void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s);
+void launch_gather_h8(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                      float* dst, const Planes& geom, float scale, hipStream_t s);
+void launch_from_planes_h8(const float* src, const Planes& geom, int C, float* dst, hipStream_t s);
+void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+                    void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
+                    hipStream_t s);
+
+}  // namespace nbe

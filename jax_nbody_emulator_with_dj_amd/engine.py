@@ -46,16 +46,27 @@ def params_fingerprint(params):
 
 
 class Engine:
-    def __init__(self, device=0, in_chan=3, out_chan=3, mid_chan=64, eps=1e-8, compute_vel=True):
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
+    def __init__(self, device=0, in_chan=3, out_chan=3, mid_chan=64, eps=1e-8, compute_vel=True, precision=None):
+        """precision: "f32" (strict float32 MFMA) or "f16x3" (float32-equivalent split-f16 MFMA);
+        default from the environment variable NBE_PRECISION, else "f32"."""
+        import os
         self._l = _lib.lib()
+        if precision is None:
+            precision = os.environ.get("NBE_PRECISION", "f32")
+        if precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
         h = C.c_void_p()
         check(self._l.nbe_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self.precision = precision
         self.in_chan, self.out_chan, self.mid_chan = int(in_chan), int(out_chan), int(mid_chan)
         self.eps, self.compute_vel = float(eps), bool(compute_vel)
         check(self._l.nbe_set_arch(self._h, self.in_chan, self.out_chan, self.mid_chan, self.eps,
                                    1 if self.compute_vel else 0))
+        check(self._l.nbe_set_precision(self._h, self.PRECISIONS[precision]))
         self._keep = None
         self.loaded = None          # fingerprint of the loaded tree
         self.premodulated = False

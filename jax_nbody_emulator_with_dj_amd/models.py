@@ -25,13 +25,16 @@ def get_engine(model, device=None):
     """One engine (context + weights + workspace) per (device, architecture, variant)."""
     if device is None:
         device = 0
-    key = (int(device), model.in_chan, model.out_chan, model.mid_chan, float(model.eps), model._compute_vel)
+    import os
+    precision = os.environ.get("NBE_PRECISION", "f32")
+    key = (int(device), model.in_chan, model.out_chan, model.mid_chan, float(model.eps), model._compute_vel, precision)
     if getattr(model, 'style_size', 2) != 2:
         raise ValueError("style_size must be 2: the style vector is ((Om-0.3)*5, Dz-1)")
     eng = _ENGINES.get(key)
     if eng is None:
         eng = _engine.Engine(device=device, in_chan=model.in_chan, out_chan=model.out_chan,
-                             mid_chan=model.mid_chan, eps=model.eps, compute_vel=model._compute_vel)
+                             mid_chan=model.mid_chan, eps=model.eps, compute_vel=model._compute_vel,
+                             precision=precision)
         _ENGINES[key] = eng
     return eng
 

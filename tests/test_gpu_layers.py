@@ -27,9 +27,11 @@ def _rand(rng, *shape):
     return rng.standard_normal(shape).astype(np.float32)
 
 
-@pytest.fixture(scope="module")
-def eng(engine_factory):
-    return engine_factory()
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
+def eng(engine_factory, request):
+    """Both arithmetic modes must meet the same float32 tolerances: strict float32 MFMA and the
+    float32-equivalent f16x3 split (operands carry 22 significant bits, float32 accumulation)."""
+    return engine_factory(precision=request.param)
 
 
 @pytest.mark.parametrize("cout,cin,k,first", [(64, 64, 3, False), (64, 3, 3, True), (3, 64, 1, False),

@@ -33,9 +33,13 @@ def small():
     return p, x, d_o[0], v_o[0]
 
 
-def test_style_vel_small(engine_factory, small):
+PRECS = ["f32", "f16x3"]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_style_vel_small(engine_factory, small, prec):
     p, x, d_o, v_o = small
-    e = engine_factory(mid_chan=8, compute_vel=True)
+    e = engine_factory(mid_chan=8, compute_vel=True, precision=prec)
     e.load_params(p, premodulated=False)
     e.set_cosmology(OM, DZ)
     d, v = e.forward(x, DZ, VF)
@@ -46,34 +50,40 @@ def test_style_vel_small(engine_factory, small):
     assert np.array_equal(d, d2) and np.array_equal(v, v2)
 
 
-def test_style_novel_small(engine_factory, small):
+@pytest.mark.parametrize("prec", PRECS)
+def test_style_novel_small(engine_factory, small, prec):
     p, x, d_o, _ = small
-    e = engine_factory(mid_chan=8, compute_vel=False)
+    e = engine_factory(mid_chan=8, compute_vel=False, precision=prec)
     e.load_params(p, premodulated=False)
     e.set_cosmology(OM, DZ)
     d = e.forward(x, DZ)
     _check(d, None, d_o, None, "style-novel mid8")
 
 
-def test_premod_vel_small(engine_factory, small):
+@pytest.mark.parametrize("prec", PRECS)
+def test_premod_vel_small(engine_factory, small, prec):
     from oracle import params as P
     p, x, d_o, v_o = small
     pp = P.premodulate_vel(p, 0.5, OM)
-    e = engine_factory(mid_chan=8, compute_vel=True)
+    e = engine_factory(mid_chan=8, compute_vel=True, precision=prec)
     e.load_params(pp, premodulated=True)
     d, v = e.forward(x, DZ, VF)
     _check(d, v, d_o, v_o, "premod-vel mid8")
 
 
 def test_full_width_c1_slice(engine_factory):
-    """mid_chan=64 (production width) on the smallest legal input, against the oracle."""
-    from oracle import params as P, model as M
-    rng = np.random.default_rng(6)
-    p = P.synthetic_params(seed=1234, mid_chan=64)
-    x = rng.standard_normal((3, 104, 104, 104)).astype(np.float32)
-    d_o, v_o = M.forward(p, x[None], OM, DZ, VF)
-    e = engine_factory(mid_chan=64, compute_vel=True)
-    e.load_params(p, premodulated=False)
-    e.set_cosmology(OM, DZ)
-    d, v = e.forward(x, DZ, VF)
-    _check(d, v, d_o[0], v_o[0], "style-vel mid64")
+    """mid_chan=64 (production width) on the smallest legal input, against the committed golden
+    fixture (float64 oracle output, tests/golden/make_golden.py), both arithmetic modes."""
+    import os
+    from oracle import params as P
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+    seed_p, seed_x, mid, d0, d1, d2 = (int(v) for v in gold["net64_meta"])
+    p = P.synthetic_params(seed=seed_p, mid_chan=mid)
+    x = np.random.default_rng(seed_x).standard_normal((1, 3, d0, d1, d2)).astype(np.float32)[0]
+    for prec in PRECS:
+        e = engine_factory(mid_chan=mid, compute_vel=True, precision=prec)
+        e.load_params(p, premodulated=False)
+        e.set_cosmology(OM, DZ)
+        d, v = e.forward(x, DZ, VF)
+        print("mid64 %s: disp rel_l2 %.3e vel rel_l2 %.3e" % (prec, rel_l2(d, gold["net64_disp"]), rel_l2(v, gold["net64_vel"])))
+        _check(d, v, gold["net64_disp"], gold["net64_vel"], "style-vel mid64 " + prec)
