@@ -6,8 +6,10 @@ ndiv=(4,4,4), StyleNBodyEmulatorVelCore, float32, on N MI355X of one node.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of process_box over the whole box (64 sub-boxes of 224^3 -> 128^3), with the input
-box and the output boxes resident in HBM.  Weights are synthetic (seeded; the pretrained blob is not
+A "step" is one pass of process_box over the whole box (64 sub-boxes of 224^3 -> 128^3, which the engine
+merges into 8 tiles of 352^3 -> 256^3 when that is exact; --max-tile 0 disables it), with the input box and
+the output boxes resident in HBM.  Arithmetic: float32-equivalent f16x3 split MFMA by default (`value`); the
+strict float32 MFMA path is timed on the same box and reported under "strict_f32".  Weights are synthetic (seeded; the pretrained blob is not
 available), which changes neither the FLOPs nor the bytes.  Rank 0 prints ONE JSON line.
 
 N > 1: the sub-box grid is sharded as bricks over the ranks (jax_nbody_emulator_with_dj_amd/sharding.py);
@@ -61,8 +63,11 @@ def main():
     ap.add_argument("--max-tile", type=int, default=256,
                     help="internal tile edge: sub-boxes are merged into tiles up to this size when that is exact "
                          "(crop %% 8 == 0); 0 = run the caller's 64 sub-boxes of 224^3 one by one")
-    ap.add_argument("--precision", default=os.environ.get("NBE_PRECISION", "f32"), choices=["f32", "f16x3"],
-                    help="f32: strict float32 MFMA; f16x3: float32-equivalent split-f16 MFMA (3 MFMAs per product)")
+    ap.add_argument("--precision", default=os.environ.get("NBE_PRECISION", "f16x3"), choices=["f32", "f16x3"],
+                    help="f16x3 (default): float32-equivalent split-f16 MFMA, 3 MFMAs per product, f32 accumulate, "
+                         "whole-network error vs the float64 oracle equal to or below the strict path's; "
+                         "f32: strict float32 MFMA")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 reference pass")
     args = ap.parse_args()
 
     import torch
@@ -89,88 +94,101 @@ def main():
     vel = not args.no_vel
     model = (StyleNBodyEmulatorVelCore if vel else StyleNBodyEmulatorCore)()
     params = model.init(1234)
-    eng = Engine(device=local_rank, compute_vel=vel, precision=args.precision)
-    eng.load_params(params, premodulated=False)
     Dz = float(np.float32(cosmology.growth_factor(Z, OM)))
     vf = float(np.float32(cosmology.vel_norm(Z, OM)))
-    eng.set_cosmology(OM, Dz)
-    eng.set_max_tile(args.max_tile)
-
     N = args.size
     size, ndiv = (N, N, N), (args.ndiv,) * 3
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
+    sb = None
     if world == 1:
-        box = torch.randn((3,) + size, device=dev, dtype=torch.float32, generator=gen)
-        disp = torch.zeros_like(box)
-        velo = torch.zeros_like(box) if vel else None
-
-        def step():
-            eng.process_box(box, size, ndiv, ((48, 48),) * 3, Dz, vf, out=(disp, velo))
+        data = torch.randn((3,) + size, device=dev, dtype=torch.float32, generator=gen)
     else:
-        sb = sharding.ShardedBox(eng, size, ndiv, rank, world, comm_stream=torch.cuda.Stream(device=dev))
-        brick = torch.randn((3,) + sb.bshape, device=dev, dtype=torch.float32, generator=gen)
-        disp = torch.zeros_like(brick)
-        velo = torch.zeros_like(brick) if vel else None
-
-        def step():
-            sb.process(brick, Dz, vf, disp, velo)
+        grid = sharding.rank_grid(world, ndiv)
+        _, bshape = sharding.brick_extent(sharding.rank_coords(rank, grid), grid, size)
+        data = torch.randn((3,) + bshape, device=dev, dtype=torch.float32, generator=gen)
+    disp = torch.zeros_like(data)
+    velo = torch.zeros_like(data) if vel else None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.profile_reset()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    eng.profile_enable(False)
-    prof = eng.profile_read()
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ok = bool(torch.isfinite(disp).all().item()) and (velo is None or bool(torch.isfinite(velo).all().item()))
+    def measure(precision, warmup, steps):
+        """W untimed + K timed passes of the whole box with one arithmetic mode."""
+        nonlocal sb
+        eng = Engine(device=local_rank, compute_vel=vel, precision=precision)
+        eng.load_params(params, premodulated=False)
+        eng.set_cosmology(OM, Dz)
+        eng.set_max_tile(args.max_tile)
+        if world == 1:
+            step = lambda: eng.process_box(data, size, ndiv, ((48, 48),) * 3, Dz, vf, out=(disp, velo))
+            plan = "%s tiles per box" % (eng.plan_tiles(size, ndiv),)
+        else:
+            sb = sharding.ShardedBox(eng, size, ndiv, rank, world, comm_stream=torch.cuda.Stream(device=dev))
+            step = lambda: sb.process(data, Dz, vf, disp, velo)
+            plan = "%s tiles per rank brick" % (eng.plan_tiles(sb.bshape, sb.nd_local),)
+        for _ in range(warmup):
+            step()
+        fence()
+        eng.profile_reset()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        eng.profile_enable(False)
+        prof = eng.profile_read()
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ok = bool(torch.isfinite(disp).all().item()) and (velo is None or bool(torch.isfinite(velo).all().item()))
+        eng.close()
+        return dt, prof, ok, plan
+
+    def roofline(prof, precision):
+        # dominant kernel, from HIP events recorded on the engine's stream inside the timed region.
+        # f16x3 issues three f16 MFMAs per float32 product: algorithmic FLOPs are priced against 1/3 of the
+        # dense f16 MFMA peak (2.5 PFLOP/s).
+        dom = max(prof, key=lambda e: e["ms"])
+        tot_ms = sum(e["ms"] for e in prof)
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+        return {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None, "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                "launches": dom["launches"], "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
+
+    dt, prof, ok, plan = measure(args.precision, args.warmup, args.steps)
+    strict = None
+    if args.precision != "f32" and world == 1 and not args.no_strict:
+        strict = measure("f32", 1, 1)             # the strict-float32 MFMA path on the same box, for reference
 
     if rank == 0:
-        vox = float(N) ** 3 * args.steps
+        vox = float(N) ** 3
+        dtype = {"f32": "f32", "f16x3": "f32-equivalent: f16x3 split MFMA (3 f16 MFMAs per product, f32 accumulate)"}
         out = {
             "metric": "voxels/sec (disp+vel) on 512^3 box, ndiv=4" if vel else "voxels/sec (disp only)",
-            "value": vox / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 via f16x3 split MFMA (f32 accumulate)",
-            "data": "synthetic",
+            "value": vox * args.steps / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": dtype[args.precision], "data": "synthetic",
             "config": {"workload": "process_box %d^3 ndiv=(%d,%d,%d) compute_vel=%s StyleNBodyEmulator%sCore, "
                                    "synthetic seeded weights, box resident in HBM" % (N, *ndiv, vel, "Vel" if vel else ""),
                        "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,),
-                       "internal_tiles": "%s tiles per %s" % (
-                           (eng.plan_tiles(size, ndiv) if world == 1 else eng.plan_tiles(sb.bshape, sb.nd_local)),
-                           "box" if world == 1 else "rank brick")},
+                       "internal_tiles": plan, "precision": args.precision},
             "finite": ok,
         }
-        # roofline of the dominant kernel, from HIP events recorded on the engine's stream inside the timed region
         if prof:
-            dom = max(prof, key=lambda e: e["ms"])
-            tot_ms = sum(e["ms"] for e in prof)
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-            # f16x3 issues three f16 MFMAs per float32 product: price algorithmic FLOPs against 1/3 of the
-            # dense f16 MFMA peak (2.5 PFLOP/s)
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
-            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                               "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
-                               "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
+            out["roofline"] = roofline(prof, args.precision)
             out["kernels"] = [{"kernel": e["kernel"], "ms": round(e["ms"], 3), "launches": e["launches"],
                                "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
                               for e in sorted(prof, key=lambda e: -e["ms"])]
+        if strict is not None:
+            sdt, sprof, sok, _ = strict
+            out["strict_f32"] = {"value": vox / sdt, "unit": "voxels/s", "ms_per_step": 1e3 * sdt, "steps": 1,
+                                 "dtype": "f32", "finite": sok, "roofline": roofline(sprof, "f32") if sprof else None}
         if world == 1 and not args.no_cpu_baseline:
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             threads = min(avail, 16)        # the 1-GPU box's CPU share; more BLAS threads only oversubscribe

@@ -155,7 +155,10 @@ static Planes ws_planes(nbe_ctx* c, int G, int D, int H, int W, int64_t* off_out
     p.G = G; p.D = D; p.H = H; p.W = W;
     p.pstride = (p.vox() + 63) & ~int64_t(63);
     const int64_t one = (int64_t)G * p.pstride * 16;
-    const int64_t off = c->arena.alloc(one * (c->vel ? 2 : 1));
+    // slack: the conv kernels stream whole row segments and may read up to 2*H*W + 2*W + ~600 voxels past the
+    // end of a plane for flat positions whose outputs are discarded (the last plane must not run off the arena)
+    const int64_t slack = ((int64_t)2 * H * W + 2 * W + 1024) * 16;
+    const int64_t off = c->arena.alloc(one * (c->vel ? 2 : 1) + slack);
     *off_out = off;
     if (!c->dry) {
         p.x = (float*)(c->ws + off);
@@ -204,8 +207,9 @@ static std::string conv_name(const PackedW& pw, bool vel, bool has_dx) {
 }
 
 // launch one convolution layer (or record it in a dry run)
-static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl, bool has_dx) {
+static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool has_dx) {
     if (c->dry) return;
+    const ConvLaunch& cl = cl_in;
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
         pe = prof_entry(c, conv_name(L.pw, c->vel, has_dx));
@@ -835,7 +839,7 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
             *bytes = (int64_t)p.G * p.pstride * 16; return p; };
         int64_t bi, bo;
         Planes pin = mk(cin, D, H, W, &bi), pout = mk(cout, OD, OH, OW, &bo), pres = pout;
-        const int64_t tot = 2 * bi + 4 * bo;
+        const int64_t tot = 2 * bi + 4 * bo + ((int64_t)2 * H * W + 2 * W + 1024) * 16;
         TCHK(hipMalloc((void**)&ws, tot)); TCHK(hipMemsetAsync(ws, 0, tot, c->stream));
         pin.x = (float*)ws; pin.dx = (float*)(ws + bi);
         pout.x = (float*)(ws + 2 * bi); pout.dx = (float*)(ws + 2 * bi + bo);

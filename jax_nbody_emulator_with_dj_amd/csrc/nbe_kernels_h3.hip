@@ -11,6 +11,7 @@
 // 16-byte unit is exactly the A/B operand of one lane for one MFMA (k = 8*(lane>>5) + j).
 
 #include "nbe_kernels_internal.h"
+#include <cstdlib>
 
 namespace nbe {
 
@@ -32,18 +33,39 @@ __device__ __forceinline__ f32x4 join4(const half4 hi, const half4 lo) {
 
 // Workgroup: 512 threads = 8 waves; tile = 64 output channels x 256 flat positions.
 // wave w: it = w & 1 (32 couts), jq = w >> 1 (64 positions = 2 MFMA column tiles).
-template <int MODE, bool VEL, bool HAS_DX>
+//
+// Pipeline: activation row segments live in a 3-deep LDS ring, weights in a 2-deep one.  During stage s
+// the DMA of W(s+1) and X(s+2) is issued BETWEEN the MFMAs of the first tap; at the end of the stage a
+// counted s_waitcnt leaves this wave's X(s+2) pieces in flight (vmcnt counts in issue order: X(s+1), issued
+// a whole stage earlier, and W(s+1) are complete), then a raw s_barrier.  Two stages of activation traffic
+// are therefore in flight at any time and the L2->LDS latency (~1.5 us per 64 KB) is off the critical path.
+// Depth of the activation ring.  Measured on MI355X (512^3 bench): depth 2 (one stage of DMA in flight) 368
+// TFLOP/s-equivalent, depth 3 (two stages in flight, counted vmcnt) 340: the kernel is limited by L2->LDS
+// throughput, not latency, so the deeper ring only adds LDS pressure.  Template parameter XDEPTH; the launcher
+// picks it from the environment variable NBE_H3_DEPTH (default 2) so both can be timed on one device.
+
+template <int MODE>
+struct H3Geom {
+    static constexpr int TAPS = mode_taps(MODE);
+    static constexpr int XV = (MODE == MODE_FLAT3) ? 288 : 256;   // 256 + 2 halo voxels, rounded to 32
+    static constexpr int WP = TAPS * 4 * 64;                      // 16-byte units: weights of one stage
+    static constexpr int XP = 4 * XV;                             // 16-byte units: activations of one stage
+};
+
+template <int MODE, bool VEL, bool HAS_DX, int H3_XDEPTH>
 __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
-    constexpr int TAPS = mode_taps(MODE);
-    constexpr int XV = (MODE == MODE_FLAT3) ? 320 : 256;
-    constexpr int WP = TAPS * 4 * 64;                // 16-byte units of one weight stage (16 channels)
-    constexpr int XP = 4 * XV;                       // 16-byte units of one activation stage
+    typedef H3Geom<MODE> G;
+    constexpr int TAPS = G::TAPS, XV = G::XV, WP = G::WP, XP = G::XP;
     constexpr bool DX = VEL && HAS_DX;
-    constexpr int OFF_W = 0, OFF_DW = WP, OFF_X = OFF_DW + (VEL ? WP : 0), OFF_DXX = OFF_X + XP;
-    constexpr int BUF = OFF_DXX + (DX ? XP : 0);
-    constexpr int NIW = WP / 64, NIX = XP / 64;
-    constexpr int NW_TOT = NIW * (VEL ? 2 : 1);
-    constexpr int NINSTR = NW_TOT + NIX * (DX ? 2 : 1);
+    constexpr int WB = WP * (VEL ? 2 : 1);           // one weight buffer  (W [, dW])
+    constexpr int XB = XP * (DX ? 2 : 1);            // one activation buffer (X [, dX])
+    constexpr int OFF_DW = WP, OFF_DXX = XP;
+    constexpr int XRING = 2 * WB;                    // start of the activation ring
+    constexpr int NW_TOT = WB / 64, NX_TOT = (XB + 63) / 64;
+    constexpr int NWS = (NW_TOT + 7) / 8, NXS = (NX_TOT + 7) / 8, NX_REM = NX_TOT % 8;
+    static_assert(WB % 64 == 0, "weight stage must be whole wave-instructions");
+    static_assert(XP % 32 == 0, "activation planes must be half-wave multiples");
+    static_assert(NWS + NXS <= 9, "more DMA slots per wave than MFMA pairs in one tap");
 
     f32x4* lds = lds_h3;
     const int tid = threadIdx.x;
@@ -58,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
     const int nstage = mode_nseg(MODE) * a.nchunk;
     const long HW = (long)a.H * a.W;
 
-    int* inbase = (int*)(lds + 2 * BUF);
+    int* inbase = (int*)(lds + XRING + H3_XDEPTH * XB);
     if (MODE == MODE_DOWN) {
         if (tid < TILE_VOX) {
             long o = q0 + tid;
@@ -71,38 +93,66 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
         __syncthreads();
     }
 
-    auto issue = [&](int s, int b) {
+    // ---- DMA slots of this wave.  Everything that does not depend on the stage is fixed here; per stage one
+    // wave-uniform byte offset is added (weights: stage*WP*16; activations: chunk planes + row segment).
+    // Activation reads may run past the end of a plane by < 2*H*W + 2*W + 400 voxels for flat positions whose
+    // outputs are discarded: every tensor is allocated with that much slack (engine: ws_planes).
+    // An activation wave-instruction covers 64 consecutive 16-byte units of the [plane][voxel] stage image; with
+    // XV = 288 it may straddle two planes (a half-wave each), which the per-lane source address handles.
+    const char* wsrc[NWS];
+    int wdst[NWS];
+    const char* xsrc[NXS];
+    int xdst[NXS];
+#pragma unroll
+    for (int t = 0; t < NWS; ++t) {
+        const int n = wave + 8 * t;
+        wsrc[t] = nullptr; wdst[t] = 0;
+        if (n < NW_TOT) {
+            const bool d = VEL && n >= WP / 64;
+            const int m = n - (d ? WP / 64 : 0);
+            wsrc[t] = (const char*)(d ? a.dw : a.w) + ((long)ct * nstage * WP + m * 64 + lane) * 16;
+            wdst[t] = (d ? OFF_DW : 0) + m * 64;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NXS; ++t) {
+        const int n = wave + 8 * t;
+        xsrc[t] = nullptr; xdst[t] = 0;
+        if (n < NX_TOT) {
+            const int u = n * 64 + lane;             // unit inside [X planes 0..3][dX planes 0..3]
+            const bool tang = DX && u >= XP;
+            const int uu = u - (tang ? XP : 0);
+            const int pl = uu / XV, vl = uu - pl * XV;
+            long v;
+            if (MODE == MODE_DOWN) v = (long)inbase[vl];
+            else v = q0 + a.in_off + vl;
+            xsrc[t] = (const char*)(tang ? a.dx : a.x) + ((long)pl * a.in_pstride + v) * 16;
+            xdst[t] = (tang ? OFF_DXX : 0) + uu;     // lane-linear: dst base = unit of lane 0
+            xdst[t] = __builtin_amdgcn_readfirstlane(xdst[t]);
+        }
+    }
+
+    auto seg_offset = [&](int s) -> long {
         const int chunk = s / mode_nseg(MODE), seg = s - chunk * mode_nseg(MODE);
         long segoff;
         if (MODE == MODE_FLAT3) segoff = (seg / 3) * HW + (seg % 3) * a.W;
         else if (MODE == MODE_DOWN) segoff = (seg >> 2) * HW + ((seg >> 1) & 1) * a.W + (seg & 1);
         else segoff = 0;
-        const long wbase = ((long)(ct * nstage + s) * WP) * 4;
-        f32x4* buf = lds + b * BUF;
-#pragma unroll
-        for (int t = 0; t < (NINSTR + 7) / 8; ++t) {
-            const int n = wave + 8 * t;              // wave-uniform instruction slot
-            if (n < NIW) {
-                dma16(a.w + wbase + (long)(n * 64 + lane) * 4, buf + OFF_W + n * 64);
-            } else if (VEL && n < NW_TOT) {
-                const int m = n - NIW;
-                dma16(a.dw + wbase + (long)(m * 64 + lane) * 4, buf + OFF_DW + m * 64);
-            } else if (n < NINSTR) {
-                const bool tang = DX && n >= NW_TOT + NIX;
-                const int m = n - NW_TOT - (tang ? NIX : 0);
-                const int pl = (m * 64) / XV;        // plane inside the 16-channel chunk: 2*h + part
-                const int vl = (m * 64) % XV + lane;
-                long v;
-                if (MODE == MODE_DOWN) v = (long)inbase[vl] + segoff;
-                else {
-                    v = q0 + a.in_off + segoff + vl;
-                    if (v > a.P - 1) v = a.P - 1;
-                }
-                const long off = ((long)(chunk * 4 + pl) * a.in_pstride + v) * 4;
-                dma16((tang ? a.dx : a.x) + off, buf + (tang ? OFF_DXX : OFF_X) + m * 64);
-            }
-        }
+        return ((long)chunk * 4 * a.in_pstride + segoff) * 16;
     };
+    auto dma_w = [&](int t, int s) {                 // weights of stage s -> weight buffer s & 1
+        if (wave + 8 * t < NW_TOT) dma16((const float*)(wsrc[t] + (long)s * WP * 16), lds + (s & 1) * WB + wdst[t]);
+    };
+    auto dma_x = [&](int t, long xoff, int ring) {   // activations (offset xoff) -> ring slot
+        if (wave + 8 * t < NX_TOT) dma16((const float*)(xsrc[t] + xoff), lds + XRING + ring * XB + xdst[t]);
+    };
+    // leave this wave's activation pieces of ONE stage in flight (its count is NXS or NXS-1 by wave)
+    auto wait_keep_x = [&]() {
+        if (NX_REM == 0 || wave < NX_REM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXS - 1) : "memory");
+    };
+    auto wait_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     // main / correction accumulators of y and dy: 2 column tiles each
     f32x16 ym[2], yc[2], dm[2], dc[2];
@@ -111,42 +161,94 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { ym[jt][e] = 0.f; yc[jt][e] = 0.f; dm[jt][e] = 0.f; dc[jt][e] = 0.f; }
 
-    auto compute = [&](int b) {
-        const half8* buf = (const half8*)(lds + b * BUF);
+    // operands of one dx tap
+    struct Ops { half8 wh, wl, dwh, dwl, xh[2], xl[2], dxh[2], dxl[2]; };
+    auto load_ops = [&](const half8* wb, const half8* xb, int tap, Ops& o) {
+        const int wo = (tap * 4 + 2 * lh) * 64 + 32 * it + li;
+        o.wh = wb[wo]; o.wl = wb[wo + 64];
+        if (VEL) { o.dwh = wb[OFF_DW + wo]; o.dwl = wb[OFF_DW + wo + 64]; }
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int wo = (tap * 4 + 2 * lh) * 64 + 32 * it + li;
-            const half8 wh = buf[OFF_W + wo], wl = buf[OFF_W + wo + 64];
-            half8 dwh, dwl;
-            if (VEL) { dwh = buf[OFF_DW + wo]; dwl = buf[OFF_DW + wo + 64]; }
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                const int xo = (2 * lh) * XV + jq * 64 + 32 * jt + li + (MODE == MODE_FLAT3 ? tap : 0);
-                const half8 xh = buf[OFF_X + xo], xl = buf[OFF_X + xo + XV];
-                ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
-                yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, yc[jt], 0, 0, 0);
-                yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, yc[jt], 0, 0, 0);
-                if (VEL) {
-                    dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xh, dm[jt], 0, 0, 0);
-                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xl, dc[jt], 0, 0, 0);
-                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwl, xh, dc[jt], 0, 0, 0);
-                }
-                if (DX) {
-                    const half8 dxh = buf[OFF_DXX + xo], dxl = buf[OFF_DXX + xo + XV];
-                    dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxh, dm[jt], 0, 0, 0);
-                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxl, dc[jt], 0, 0, 0);
-                    dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dxh, dc[jt], 0, 0, 0);
-                }
-            }
+        for (int jt = 0; jt < 2; ++jt) {
+            const int xo = (2 * lh) * XV + jq * 64 + 32 * jt + li + (MODE == MODE_FLAT3 ? tap : 0);
+            o.xh[jt] = xb[xo]; o.xl[jt] = xb[xo + XV];
+            if (DX) { o.dxh[jt] = xb[OFF_DXX + xo]; o.dxl[jt] = xb[OFF_DXX + xo + XV]; }
         }
     };
+    // the i-th of the 18 MFMAs of one tap (i is a compile-time constant after unrolling): jt = i / 9
+    auto mfma1 = [&](const Ops& o, int i) {
+        const int jt = i / 9, k = i % 9;
+        if (k == 0) ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xh[jt], ym[jt], 0, 0, 0);
+        if (k == 1) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xl[jt], yc[jt], 0, 0, 0);
+        if (k == 2) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.xh[jt], yc[jt], 0, 0, 0);
+        if (VEL) {
+            if (k == 3) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xh[jt], dm[jt], 0, 0, 0);
+            if (k == 4) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xl[jt], dc[jt], 0, 0, 0);
+            if (k == 5) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwl, o.xh[jt], dc[jt], 0, 0, 0);
+        }
+        if (DX) {
+            if (k == 6) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxh[jt], dm[jt], 0, 0, 0);
+            if (k == 7) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxl[jt], dc[jt], 0, 0, 0);
+            if (k == 8) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.dxh[jt], dc[jt], 0, 0, 0);
+        }
+    };
+    auto mfma_ops = [&](const Ops& o) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) mfma1(o, i);
+    };
 
-    issue(0, 0);
-    __syncthreads();
+    // ---- prologue: X(0), W(0), X(1) -------------------------------------------------------------------
+    {
+        const long x0 = seg_offset(0);
+#pragma unroll
+        for (int t = 0; t < NXS; ++t) dma_x(t, x0, 0);
+#pragma unroll
+        for (int t = 0; t < NWS; ++t) dma_w(t, 0);
+        if (H3_XDEPTH == 3 && nstage > 1) {
+            const long x1 = seg_offset(1);
+#pragma unroll
+            for (int t = 0; t < NXS; ++t) dma_x(t, x1, 1);
+            wait_keep_x();
+        } else {
+            wait_all();
+        }
+        barrier();
+    }
+
+    int ring = 0;                                    // ring slot of X(s)
     for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) issue(s + 1, (s + 1) & 1);
-        compute(s & 1);
-        __syncthreads();
+        // activations prefetched during this stage: X(s + XDEPTH - 1) into the ring slot freed by stage s-1
+        const bool pw = s + 1 < nstage, px = s + H3_XDEPTH - 1 < nstage;
+        const long xoff2 = px ? seg_offset(s + H3_XDEPTH - 1) : 0;
+        const int ring2 = H3_XDEPTH == 3 ? (ring >= 1 ? ring - 1 : 2) : (ring ^ 1);
+        const half8* wb = (const half8*)(lds + (s & 1) * WB);
+        const half8* xb = (const half8*)(lds + XRING + ring * XB);
+        Ops o0, o1;
+        load_ops(wb, xb, 0, o0);
+        if (TAPS > 1) load_ops(wb, xb, 1, o1);
+        __builtin_amdgcn_sched_barrier(0);
+        // first tap: one DMA instruction after every second MFMA -- W(s+1) first, then X(s+2)
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            mfma1(o0, i);
+            if (i & 1) {
+                const int t = i >> 1;
+                if (t < NWS) { if (pw) dma_w(t, s + 1); }
+                else if (t - NWS < NXS) { if (px) dma_x(t - NWS, xoff2, ring2); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (TAPS > 1) {
+            load_ops(wb, xb, 2, o0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_ops(o1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_ops(o0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (H3_XDEPTH == 3 && px) wait_keep_x(); else wait_all();
+        barrier();
+        ring = ring == H3_XDEPTH - 1 ? 0 : ring + 1;
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -206,14 +308,13 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
     }
 }
 
-template <int MODE, bool VEL, bool HAS_DX>
+template <int MODE, bool VEL, bool HAS_DX, int XDEPTH>
 static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
-    constexpr int TAPS = mode_taps(MODE);
-    constexpr int XV = (MODE == MODE_FLAT3) ? 320 : 256;
-    constexpr int WP = TAPS * 4 * 64, XP = 4 * XV;
-    constexpr int BUF = WP * (VEL ? 2 : 1) + XP * ((VEL && HAS_DX) ? 2 : 1);
-    constexpr size_t smem = (size_t)2 * BUF * 16 + TILE_VOX * sizeof(int);
-    auto kern = conv_h3_kernel<MODE, VEL, HAS_DX>;
+    typedef H3Geom<MODE> G;
+    constexpr int WB = G::WP * (VEL ? 2 : 1), XB = G::XP * ((VEL && HAS_DX) ? 2 : 1);
+    constexpr size_t smem = (size_t)(2 * WB + XDEPTH * XB) * 16 + TILE_VOX * sizeof(int);
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
+    auto kern = conv_h3_kernel<MODE, VEL, HAS_DX, XDEPTH>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -225,14 +326,17 @@ static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
 
 void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
     const int ct = pw.ctiles;
-#define NBE_DISPATCH_H3(MODE)                                                   \
-    if (vel) { if (has_dx) launch_h3_t<MODE, true, true>(ka, ct, s);            \
-               else launch_h3_t<MODE, true, false>(ka, ct, s); }                \
-    else launch_h3_t<MODE, false, false>(ka, ct, s);
+    static const int depth = (getenv("NBE_H3_DEPTH") && atoi(getenv("NBE_H3_DEPTH")) == 3) ? 3 : 2;
+#define NBE_DISPATCH_H3D(MODE, D)                                               \
+    if (vel) { if (has_dx) launch_h3_t<MODE, true, true, D>(ka, ct, s);         \
+               else launch_h3_t<MODE, true, false, D>(ka, ct, s); }             \
+    else launch_h3_t<MODE, false, false, D>(ka, ct, s);
+#define NBE_DISPATCH_H3(MODE) if (depth == 3) { NBE_DISPATCH_H3D(MODE, 3) } else { NBE_DISPATCH_H3D(MODE, 2) }
     if (pw.mode == MODE_FLAT3) { NBE_DISPATCH_H3(MODE_FLAT3) }
     else if (pw.mode == MODE_FLAT1) { NBE_DISPATCH_H3(MODE_FLAT1) }
     else { NBE_DISPATCH_H3(MODE_DOWN) }
 #undef NBE_DISPATCH_H3
+#undef NBE_DISPATCH_H3D
 }
 
 // packed layout: [set][ct][stage = chunk*nseg + seg][tap][u = 2*h + part][co 64][j 8];

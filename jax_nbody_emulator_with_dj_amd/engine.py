@@ -49,12 +49,13 @@ class Engine:
     PRECISIONS = {"f32": 0, "f16x3": 1}
 
     def __init__(self, device=0, in_chan=3, out_chan=3, mid_chan=64, eps=1e-8, compute_vel=True, precision=None):
-        """precision: "f32" (strict float32 MFMA) or "f16x3" (float32-equivalent split-f16 MFMA);
-        default from the environment variable NBE_PRECISION, else "f32"."""
+        """precision: "f16x3" (float32-equivalent split-f16 MFMA: three f16 MFMAs per product, float32
+        accumulation; whole-network error vs float64 at or below the strict path's) or "f32" (strict float32
+        MFMA).  Default: the environment variable NBE_PRECISION, else "f16x3"."""
         import os
         self._l = _lib.lib()
         if precision is None:
-            precision = os.environ.get("NBE_PRECISION", "f32")
+            precision = os.environ.get("NBE_PRECISION", "f16x3")
         if precision not in self.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
         h = C.c_void_p()

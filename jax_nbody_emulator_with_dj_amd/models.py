@@ -26,7 +26,7 @@ def get_engine(model, device=None):
     if device is None:
         device = 0
     import os
-    precision = os.environ.get("NBE_PRECISION", "f32")
+    precision = os.environ.get("NBE_PRECISION", "f16x3")
     key = (int(device), model.in_chan, model.out_chan, model.mid_chan, float(model.eps), model._compute_vel, precision)
     if getattr(model, 'style_size', 2) != 2:
         raise ValueError("style_size must be 2: the style vector is ((Om-0.3)*5, Dz-1)")

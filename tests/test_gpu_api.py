@@ -30,8 +30,17 @@ def _close(got, want, l2, mx, tag):
     assert e[0] <= l2 and e[1] <= mx, "%s: rel_l2=%.3e max/rms=%.3e" % (tag, *e)
 
 
+@pytest.fixture(params=["f16x3", "f32"])
+def precision(request, monkeypatch):
+    """The API picks the arithmetic mode from NBE_PRECISION (default f16x3); both must meet the tolerances."""
+    from jax_nbody_emulator_with_dj_amd import models
+    monkeypatch.setenv("NBE_PRECISION", request.param)
+    yield request.param
+    models.release_engines()
+
+
 @pytest.mark.parametrize("tag", ["net8", "net64"])
-def test_apply_matches_golden(tag):
+def test_apply_matches_golden(tag, precision):
     seed_p, seed_x, mid, d0, d1, d2 = (int(v) for v in GOLD[tag + "_meta"])
     p = _synthetic(seed_p, mid)
     x = np.random.default_rng(seed_x).standard_normal((1, 3, d0, d1, d2)).astype(np.float32)
@@ -54,7 +63,7 @@ def test_apply_matches_golden(tag):
     _close(d4[0], GOLD[tag + "_disp"], 2e-5, 2e-4, tag + " premod novel disp")
 
 
-def test_process_box_matches_golden_and_reference_semantics():
+def test_process_box_matches_golden_and_reference_semantics(precision):
     seed_p, seed_x, mid, s0, s1, s2, n0, n1, n2 = (int(v) for v in GOLD["pbox_meta"])
     p = _synthetic(seed_p, mid)
     box = np.random.default_rng(seed_x).standard_normal((3, s0, s1, s2)).astype(np.float32)
