@@ -31,6 +31,53 @@ __device__ __forceinline__ f32x4 join4(const half4 hi, const half4 lo) {
     return v;
 }
 
+// Epilogue of one 32x32 accumulator tile for output voxel `o` (this lane's column): join main + correction,
+// bias, residual, LeakyReLU (+ tangent) in float32, then split to hi/lo and store 4 channels (8 B) per part.
+// it = cout half of the wave, lh = lane half; register 4k+e of the tile is cout 32*it + 8k + 4*lh + e.
+template <bool VEL>
+__device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int lh, long o, const f32x16& ym,
+                                         const f32x16& yc, const f32x16& dm, const f32x16& dc) {
+    const bool act = a.flags & F_ACT, res = a.flags & F_RES;
+    char* const yb = (char*)a.y;
+    char* const dyb = (char*)a.dy;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int unit = ct * 8 + 4 * it + k;                    // 8-channel group of the output
+        if (unit >= a.cout_groups) continue;
+        const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * lh);
+        f32x4 v, dv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = ym[4 * k + e] + yc[4 * k + e] * H3_INV + bv[e];
+            dv[e] = dm[4 * k + e] + dc[4 * k + e] * H3_INV;
+        }
+        if (res) {
+            const long rb = ((long)(2 * unit) * a.res_pstride + o) * 16 + 8 * lh;
+            const long rl = rb + a.res_pstride * 16;
+            v += join4(*(const half4*)((const char*)a.r + rb), *(const half4*)((const char*)a.r + rl));
+            if (VEL) dv += join4(*(const half4*)((const char*)a.dr + rb), *(const half4*)((const char*)a.dr + rl));
+        }
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (VEL) dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+            }
+        }
+        const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + o) * 16 + 8 * lh;
+        const long ol = ob + a.out_pstride * 16;
+        half4 hi, lo;
+        split4(v, hi, lo);
+        *(half4*)(yb + ob) = hi;
+        *(half4*)(yb + ol) = lo;
+        if (VEL) {
+            split4(dv, hi, lo);
+            *(half4*)(dyb + ob) = hi;
+            *(half4*)(dyb + ol) = lo;
+        }
+    }
+}
+
 // Workgroup: 512 threads = 8 waves; tile = 64 output channels x 256 flat positions.
 // wave w: it = w & 1 (32 couts), jq = w >> 1 (64 positions = 2 MFMA column tiles).
 //
@@ -252,9 +299,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    const bool act = a.flags & F_ACT, res = a.flags & F_RES;
-    char* const yb = (char*)a.y;
-    char* const dyb = (char*)a.dy;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         const long q = q0 + jq * 64 + 32 * jt + li;
@@ -269,42 +313,202 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
             o = ((long)(z * a.osz + a.oz) * a.Ho + (yy * a.osz + a.oy)) * a.Wo + (xx * a.osz + a.ox);
         }
         if (!valid) continue;
+        h3_store<VEL>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3x3 convolution on 2-D patches (the production kernel for MODE_FLAT3 layers)
+// ------------------------------------------------------------------------------------------------
+// The flat tiling above re-fetches every activation row segment once per (dz,dy) pair: 95 B of activation DMA
+// per MFMA on top of 57 B of weights, and the kernel is bound by L2->LDS throughput.  Here a workgroup owns an
+// 8-row x 32-column patch of ONE output plane; for each 16-channel chunk and each dz it stages the 10 x 34
+// input patch once and serves all nine (dy,dx) taps from it (LDS address = row*34 + col, taps are address
+// shifts).  Weights stream exactly as before: one 24.6 KB stage per (chunk, dz, dy), same packed layout.
+// DMA per MFMA drops to ~34 B (activations) + 57 B (weights).  Tiles are ordered z-fastest so that the 32
+// workgroups of an XCD work on neighbouring planes of the same (y,x) patch and share two of their three input
+// planes through that XCD's L2.
+constexpr int HP_ROWS = 8, HP_COLS = 32;
+constexpr int HP_RS = HP_COLS + 2;                   // LDS row stride (units)
+constexpr int HP_PL = (HP_ROWS + 2) * HP_RS;         // units per plane of the patch image: 340
+constexpr int HP_XP = 4 * HP_PL;                     // valid units of one tensor's patch (4 planes): 1360
+constexpr int HP_XPP = (HP_XP + 63) / 64 * 64;       // padded to whole wave-instructions: 1408
+
+template <bool VEL, bool HAS_DX>
+__global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
+    constexpr bool DX = VEL && HAS_DX;
+    constexpr int WP = 3 * 4 * 64;
+    constexpr int WB = WP * (VEL ? 2 : 1);
+    constexpr int XB = HP_XPP * (DX ? 2 : 1);
+    constexpr int OFF_DW = WP, OFF_DXX = HP_XPP;
+    constexpr int XBASE = 2 * WB;
+    constexpr int NW_TOT = WB / 64, NX_TOT = XB / 64;            // 24 and 44 wave-instructions
+    constexpr int NWS = (NW_TOT + 7) / 8;                        // weight slots per wave and stage
+    constexpr int NXS = (NX_TOT + 23) / 24;                      // activation slots per wave and stage (x3 per group)
+    static_assert(NWS + NXS <= 9, "more DMA slots per wave than MFMA pairs in one tap");
+
+    f32x4* lds = lds_h3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int it = wave & 1, jq = wave >> 1;
+
+    // tile -> (ty, tx, z), z fastest
+    const int tile = xcd_tile(blockIdx.x, a.ntiles);
+    const int ct = blockIdx.y;
+    const int z = tile % a.Dv, tyx = tile / a.Dv;
+    const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
+    const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS;
+    const int nstage = 9 * a.nchunk;
+    const long HW = (long)a.H * a.W;
+
+    // ---- DMA slots.  Weights: instruction n = wave + 8t of every stage.  Activations: the 44 instructions of
+    // the NEXT (chunk,dz) patch are spread over the three dy stages of the current one: instruction
+    // n = dy*NXS*8 + t*8 + wave.  Per-lane source = patch-relative voxel (row*W + col) in plane pl; per patch a
+    // wave-uniform offset (chunk planes + patch origin) is added.
+    const char* wsrc[NWS];
+    int wdst[NWS];
+    const char* xsrc[3][NXS];
+    int xdst[3][NXS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int unit = ct * 8 + 4 * it + k;                // 8-channel group of the output
-            if (unit >= a.cout_groups) continue;
-            const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * lh);
-            f32x4 v, dv;
+    for (int t = 0; t < NWS; ++t) {
+        const int n = wave + 8 * t;
+        wsrc[t] = nullptr; wdst[t] = 0;
+        if (n < NW_TOT) {
+            const bool d = VEL && n >= WP / 64;
+            const int m = n - (d ? WP / 64 : 0);
+            wsrc[t] = (const char*)(d ? a.dw : a.w) + ((long)ct * nstage * WP + m * 64 + lane) * 16;
+            wdst[t] = (d ? OFF_DW : 0) + m * 64;
+        }
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = ym[jt][4 * k + e] + yc[jt][4 * k + e] * H3_INV + bv[e];
-                dv[e] = dm[jt][4 * k + e] + dc[jt][4 * k + e] * H3_INV;
-            }
-            if (res) {
-                const long rb = ((long)(2 * unit) * a.res_pstride + o) * 16 + 8 * lh;
-                const long rl = rb + a.res_pstride * 16;
-                v += join4(*(const half4*)((const char*)a.r + rb), *(const half4*)((const char*)a.r + rl));
-                if (VEL) dv += join4(*(const half4*)((const char*)a.dr + rb), *(const half4*)((const char*)a.dr + rl));
-            }
-            if (act) {
+    for (int p = 0; p < 3; ++p) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (VEL) dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
-                    v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
-                }
-            }
-            const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + o) * 16 + 8 * lh;
-            const long ol = ob + a.out_pstride * 16;
-            half4 hi, lo;
-            split4(v, hi, lo);
-            *(half4*)(yb + ob) = hi;
-            *(half4*)(yb + ol) = lo;
-            if (VEL) {
-                split4(dv, hi, lo);
-                *(half4*)(dyb + ob) = hi;
-                *(half4*)(dyb + ol) = lo;
+        for (int t = 0; t < NXS; ++t) {
+            const int n = (p * NXS + t) * 8 + wave;
+            xsrc[p][t] = nullptr; xdst[p][t] = 0;
+            if (n < NX_TOT) {
+                const int u = n * 64 + lane;
+                const bool tang = DX && u >= HP_XPP;
+                int uu = u - (tang ? HP_XPP : 0);
+                const int ud = uu;                               // LDS position (padding lanes land in the pad)
+                if (uu >= HP_XP) uu = HP_XP - 1;
+                const int pl = uu / HP_PL, rem = uu - pl * HP_PL;
+                const int row = rem / HP_RS, col = rem - row * HP_RS;
+                xsrc[p][t] = (const char*)(tang ? a.dx : a.x) + ((long)pl * a.in_pstride + (long)row * a.W + col) * 16;
+                xdst[p][t] = __builtin_amdgcn_readfirstlane((tang ? OFF_DXX : 0) + ud);
             }
         }
+    }
+    auto patch_offset = [&](int g) -> long {                     // g = chunk*3 + dz
+        const int chunk = g / 3, dz = g - chunk * 3;
+        return ((long)chunk * 4 * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
+    };
+    auto dma_w = [&](int t, int s) {
+        if (wave + 8 * t < NW_TOT) dma16((const float*)(wsrc[t] + (long)s * WP * 16), lds + (s & 1) * WB + wdst[t]);
+    };
+    auto dma_x = [&](int p, int t, long xoff, int xb) {
+        if ((p * NXS + t) * 8 + wave < NX_TOT) dma16((const float*)(xsrc[p][t] + xoff), lds + XBASE + xb * XB + xdst[p][t]);
+    };
+
+    f32x16 ym[2], yc[2], dm[2], dc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ym[jt][e] = 0.f; yc[jt][e] = 0.f; dm[jt][e] = 0.f; dc[jt][e] = 0.f; }
+
+    struct Ops { half8 wh, wl, dwh, dwl, xh[2], xl[2], dxh[2], dxl[2]; };
+    // operands of tap (dy, dx): weights of the current stage, activations from the resident patch
+    auto load_ops = [&](const half8* wb, const half8* xb, int dy, int dx, Ops& o) {
+        const int wo = (dx * 4 + 2 * lh) * 64 + 32 * it + li;
+        o.wh = wb[wo]; o.wl = wb[wo + 64];
+        if (VEL) { o.dwh = wb[OFF_DW + wo]; o.dwl = wb[OFF_DW + wo + 64]; }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int xo = (2 * lh) * HP_PL + (2 * jq + jt + dy) * HP_RS + li + dx;
+            o.xh[jt] = xb[xo]; o.xl[jt] = xb[xo + HP_PL];
+            if (DX) { o.dxh[jt] = xb[OFF_DXX + xo]; o.dxl[jt] = xb[OFF_DXX + xo + HP_PL]; }
+        }
+    };
+    auto mfma1 = [&](const Ops& o, int i) {
+        const int jt = i / 9, k = i % 9;
+        if (k == 0) ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xh[jt], ym[jt], 0, 0, 0);
+        if (k == 1) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xl[jt], yc[jt], 0, 0, 0);
+        if (k == 2) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.xh[jt], yc[jt], 0, 0, 0);
+        if (VEL) {
+            if (k == 3) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xh[jt], dm[jt], 0, 0, 0);
+            if (k == 4) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xl[jt], dc[jt], 0, 0, 0);
+            if (k == 5) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwl, o.xh[jt], dc[jt], 0, 0, 0);
+        }
+        if (DX) {
+            if (k == 6) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxh[jt], dm[jt], 0, 0, 0);
+            if (k == 7) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxl[jt], dc[jt], 0, 0, 0);
+            if (k == 8) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.dxh[jt], dc[jt], 0, 0, 0);
+        }
+    };
+    auto mfma_ops = [&](const Ops& o) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) mfma1(o, i);
+    };
+
+    // ---- prologue: patch of group 0 (all its instructions) and weights of stage 0
+    {
+        const long x0off = patch_offset(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int t = 0; t < NXS; ++t) dma_x(p, t, x0off, 0);
+#pragma unroll
+        for (int t = 0; t < NWS; ++t) dma_w(t, 0);
+        __syncthreads();
+    }
+
+    int g = 0, dy = 0;                                           // stage s = 3*g + dy
+    for (int s = 0; s < nstage; ++s) {
+        const bool pw = s + 1 < nstage, px = 3 * (g + 1) < nstage;
+        const long xoff = px ? patch_offset(g + 1) : 0;
+        const half8* wb = (const half8*)(lds + (s & 1) * WB);
+        const half8* xb = (const half8*)(lds + XBASE + (g & 1) * XB);
+        Ops o0, o1;
+        load_ops(wb, xb, dy, 0, o0);
+        load_ops(wb, xb, dy, 1, o1);
+        __builtin_amdgcn_sched_barrier(0);
+        // first tap: one DMA instruction after every second MFMA -- W(s+1), then this stage's share of X(g+1)
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            mfma1(o0, i);
+            if (i & 1) {
+                const int t = i >> 1;
+                if (t < NWS) { if (pw) dma_w(t, s + 1); }
+                else if (t - NWS < NXS) {
+                    if (px) {
+                        if (dy == 0) dma_x(0, t - NWS, xoff, (g + 1) & 1);
+                        else if (dy == 1) dma_x(1, t - NWS, xoff, (g + 1) & 1);
+                        else dma_x(2, t - NWS, xoff, (g + 1) & 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_ops(wb, xb, dy, 2, o0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_ops(o1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_ops(o0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                         // vmcnt(0): W(s+1) and this stage's X pieces landed
+        if (++dy == 3) { dy = 0; ++g; }
+    }
+
+    // ---- epilogue: rows y0 + 2*jq + jt, column x0 + li of output plane z
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int yy = y0 + 2 * jq + jt, xx = x0 + li;
+        if (yy >= a.Hv || xx >= a.Wv) continue;
+        const long o = ((long)z * a.Ho + yy) * a.Wo + xx;
+        h3_store<VEL>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
     }
 }
 
@@ -324,9 +528,33 @@ static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
 }
 
+template <bool VEL, bool HAS_DX>
+static void launch_h3p_t(ConvKArgs ka, int ctiles, hipStream_t s) {
+    constexpr int WB = 3 * 4 * 64 * (VEL ? 2 : 1), XB = HP_XPP * ((VEL && HAS_DX) ? 2 : 1);
+    constexpr size_t smem = (size_t)(2 * WB + 2 * XB) * 16;
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
+    auto kern = conv_h3p_kernel<VEL, HAS_DX>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
+    ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
+    ka.ntiles = ka.Dv * ka.tny * ka.tnx;
+    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
+}
+
 void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
     const int ct = pw.ctiles;
     static const int depth = (getenv("NBE_H3_DEPTH") && atoi(getenv("NBE_H3_DEPTH")) == 3) ? 3 : 2;
+    static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
+    if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
+        if (vel) { if (has_dx) launch_h3p_t<true, true>(ka, ct, s); else launch_h3p_t<true, false>(ka, ct, s); }
+        else launch_h3p_t<false, false>(ka, ct, s);
+        return;
+    }
 #define NBE_DISPATCH_H3D(MODE, D)                                               \
     if (vel) { if (has_dx) launch_h3_t<MODE, true, true, D>(ka, ct, s);         \
                else launch_h3_t<MODE, true, false, D>(ka, ct, s); }             \

@@ -22,6 +22,7 @@ struct ConvKArgs {
     const float* r; const float* dr; long res_pstride;
     const float* bias; const float* w; const float* dw;
     int nchunk; int cout_groups; int flags; int ntiles;
+    int tny, tnx;            // patch kernel: number of 8-row / 32-column tiles per output plane
 };
 
 __device__ __forceinline__ void dma16(const float* src, f32x4* dst_wave_base) {
