@@ -157,8 +157,15 @@ def main():
         tot_ms = sum(e["ms"] for e in prof)
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+        # HBM-side bytes per launch of the dominant kernel cannot be read from inside the process; they come from
+        # the committed rocprofv3 --pmc passes of this exact workload (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # profiles/r01_pmc_fetch_write_default_f16x3.txt) and are reported only when the configuration matches.
+        traffic = None
+        if (precision, N, args.ndiv, args.max_tile, vel, world) == ("f16x3", 512, 4, 256, True, 1) \
+                and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
+            traffic = 26.96e9
         return {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None, "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                "frac": ach / peak, "traffic": traffic, "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                 "launches": dom["launches"], "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
 
     dt, prof, ok, plan = measure(args.precision, args.warmup, args.steps)
