@@ -100,6 +100,11 @@ def exchange_halo(brick, grid, coords, pad=PAD, group=None):
         cp[a] += 1
         minus, plus = coords_rank(cm, grid), coords_rank(cp, grid)
         s_first, s_last = H[first].contiguous(), H[last].contiguous()
+        # gloo moves host memory: stage CUDA slabs through the CPU (test rigs with several ranks on one GPU);
+        # with nccl (= RCCL) the slabs go device to device over xGMI
+        stage = brick.is_cuda and dist.get_backend(group) == "gloo"
+        if stage:
+            s_first, s_last = s_first.cpu(), s_last.cpu()
         r_hi, r_lo = torch.empty_like(s_first), torch.empty_like(s_last)
         # order discipline (P2P between one pair matches in order; minus == plus when grid[a] == 2):
         # sends  (1) first -> minus, (2) last -> plus ; receives (1) high <- plus, (2) low <- minus

@@ -1,0 +1,89 @@
+"""GPU: the N > 1 path end to end on ONE card.  RCCL refuses several ranks on one device, so the ranks
+are separate processes that share cuda:0 and exchange their halos over gloo (CPU-staged); everything
+else -- brick bookkeeping, halo content, nbe_process_region on the haloed brick, internal tile
+merging per brick -- is the code the multi-GPU bench runs.  The assembled result must equal the
+single-process process_box of the whole box."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Z, OM = 0.5, 0.3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import jax_nbody_emulator_with_dj_amd as J
+        from jax_nbody_emulator_with_dj_amd import sharding
+        from jax_nbody_emulator_with_dj_amd.engine import Engine
+        from oracle import params as P
+        torch.cuda.set_device(0)
+        p = P.synthetic_params(seed=seed_p, mid_chan=8)
+        eng = Engine(device=0, mid_chan=8, compute_vel=True)
+        eng.load_params(p, premodulated=False)
+        Dz, vf = float(J.growth_factor(Z, OM)), float(J.vel_norm(Z, OM))
+        eng.set_cosmology(OM, Dz)
+        full = np.random.default_rng(seed_x).standard_normal((3,) + size).astype(np.float32)
+        sb = sharding.ShardedBox(eng, size, ndiv, rank, world)
+        o, b = sb.origin, sb.bshape
+        brick = torch.from_numpy(np.ascontiguousarray(
+            full[:, o[0]:o[0] + b[0], o[1]:o[1] + b[1], o[2]:o[2] + b[2]])).cuda()
+        disp, vel = torch.zeros_like(brick), torch.zeros_like(brick)
+        sb.process(brick, Dz, vf, disp, vel)
+        torch.cuda.synchronize()
+        q.put((rank, o, disp.cpu().numpy(), vel.cpu().numpy()))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size,ndiv", [(2, (128, 64, 64), (2, 1, 1)),
+                                             (4, (128, 128, 64), (4, 2, 1))])
+def test_sharded_equals_single_process(world, size, ndiv):
+    import torch.multiprocessing as mp
+    import jax_nbody_emulator_with_dj_amd as J
+    from oracle import params as P
+    seed_p, seed_x = 61, 62
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, size, ndiv, seed_p, seed_x, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    parts = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    # single-process reference through the plain API
+    p = P.synthetic_params(seed=seed_p, mid_chan=8)
+    full = np.random.default_rng(seed_x).standard_normal((3,) + size).astype(np.float32)
+    proc = J.SubboxProcessor(J.StyleNBodyEmulatorVelCore(mid_chan=8), p, J.SubboxConfig(size=size, ndiv=ndiv))
+    d_ref, v_ref = proc.process_box(full, Z, OM, show_progress=False)
+    d_all, v_all = np.zeros_like(d_ref), np.zeros_like(v_ref)
+    cover = np.zeros(size, np.int32)
+    for rank, o, d, v in parts:
+        b = d.shape[1:]
+        sl = (slice(None), slice(o[0], o[0] + b[0]), slice(o[1], o[1] + b[1]), slice(o[2], o[2] + b[2]))
+        d_all[sl], v_all[sl] = d, v
+        cover[sl[1:]] += 1
+    assert np.all(cover == 1)
+    # identical arithmetic per voxel (same kernels, same K order): equal to rounding of the tile boundaries
+    np.testing.assert_allclose(d_all, d_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v_all, v_ref, rtol=1e-5, atol=1e-4)
