@@ -188,6 +188,41 @@ def test_internal_tile_merging_is_exact():
     _close(v1, v0, 1e-6, 1e-5, "merged tiles vel")
 
 
+def test_config3_at_full_size_merged_tiles_vs_callers_grid():
+    """BASELINE config 3: 512^3 box, ndiv=(4,4,4), compute_vel=True, production width, resident tensors.
+    Size-independent property: the engine's default execution (8 merged tiles of 352^3 input) and the
+    caller's grid run exactly (64 sub-boxes of 224^3) give the same fields; plus velocity proportional to
+    vel_fac through the whole sub-box loop."""
+    import torch
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    m = J.StyleNBodyEmulatorVelCore()
+    p = m.init(1234)
+    size, ndiv = (512,) * 3, (4,) * 3
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0)
+    box = torch.randn((3,) + size, device="cuda", generator=gen)
+    eng = get_engine(m, 0)
+    eng.ensure_params(p, False)
+    Dz, vf = float(J.growth_factor(Z, OM)), float(J.vel_norm(Z, OM))
+    eng.set_cosmology(OM, Dz)
+    assert eng.plan_tiles(size, ndiv) == (2, 2, 2)
+    pad = ((48, 48),) * 3
+    d1, v1 = eng.process_box(box, size, ndiv, pad, Dz, vf)
+    try:
+        eng.set_max_tile(0)
+        assert eng.plan_tiles(size, ndiv) == (4, 4, 4)
+        d0, v0 = eng.process_box(box, size, ndiv, pad, Dz, 2.0 * vf)
+    finally:
+        eng.set_max_tile(256)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(d1).all()) and bool(torch.isfinite(v1).all())
+    rms_d, rms_v = float(d1.pow(2).mean().sqrt()), float(v1.pow(2).mean().sqrt())
+    assert float((d1 - d0).abs().max()) <= 1e-5 * rms_d
+    assert float((2.0 * v1 - v0).abs().max()) <= 2e-5 * 2.0 * rms_v
+    del d0, v0, d1, v1, box
+    torch.cuda.empty_cache()
+
+
 def test_unsupported_shapes_raise():
     m = J.StyleNBodyEmulatorCore(mid_chan=8)
     p = _synthetic(1, 8)
