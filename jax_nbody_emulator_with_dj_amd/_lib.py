@@ -82,6 +82,8 @@ def build(force=False, verbose=False):
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if os.environ.get("NBE_BUILD_DBG") == "1":      # timing-experiment switches in the kernels (never for results)
+        cmd.insert(1, "-DNBE_DBG=1")
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

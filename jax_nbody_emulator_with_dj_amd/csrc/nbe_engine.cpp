@@ -209,7 +209,10 @@ static std::string conv_name(const PackedW& pw, bool vel, bool has_dx) {
 // launch one convolution layer (or record it in a dry run)
 static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool has_dx) {
     if (c->dry) return;
-    const ConvLaunch& cl = cl_in;
+    ConvLaunch cl = cl_in;
+    // timing experiments of NBE_DBG builds (bits >= 8); production kernels ignore them
+    static const int dbgf = getenv("NBE_DEBUG_FLAGS") ? atoi(getenv("NBE_DEBUG_FLAGS")) & 0xF00 : 0;
+    cl.flags |= dbgf;
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
         pe = prof_entry(c, conv_name(L.pw, c->vel, has_dx));

@@ -13,6 +13,10 @@
 #include "nbe_kernels_internal.h"
 #include <cstdlib>
 
+#ifndef NBE_DBG
+#define NBE_DBG 0          // 1: compile the timing-experiment switches (python: NBE_BUILD_DBG=1)
+#endif
+
 namespace nbe {
 
 extern __shared__ __attribute__((aligned(16))) f32x4 lds_h3[];
@@ -334,7 +338,18 @@ constexpr int HP_PL = (HP_ROWS + 2) * HP_RS;         // units per plane of the p
 constexpr int HP_XP = 4 * HP_PL;                     // valid units of one tensor's patch (4 planes): 1360
 constexpr int HP_XPP = (HP_XP + 63) / 64 * 64;       // padded to whole wave-instructions: 1408
 
-template <bool VEL, bool HAS_DX>
+// SCHED selects how the DMA of one stage is issued (A/B on one device: env NBE_H3_SCHED):
+//   0  burst: W(s+1) and a third of X(g+1) right after the barrier, interleaved with the first tap's MFMAs;
+//      every stage ends with vmcnt(0) (__syncthreads).
+//   1  de-bursted: W(s+1) in the first tap; X(g+1) in halves during the dy = 0 and dy = 1 stages, issued in the
+//      second/third tap and left in flight across the barrier with a counted vmcnt (they are needed only when the
+//      (chunk,dz) group changes).
+// Measured (same device, 512^3 bench, TFLOP/s-equivalent of this kernel): SCHED 0 = 354, SCHED 1 = 345.
+// Debug-build probes (NBE_BUILD_DBG=1, NBE_DEBUG_FLAGS): no DMA at all 482; weight DMA only 481; activation DMA
+// only 475; both 352 -- any mix of the two streams costs 20-30 % whatever its size (2W+1X slots: 394, 3W+1X: 385,
+// 2W+2X: 387), and neither de-bursting (SCHED 1), nor leaving the DMA in flight across the barrier, nor a deeper
+// ring, nor 40 % fewer bytes (this kernel vs the flat one) changes that.  Unexplained; default stays SCHED 0.
+template <bool VEL, bool HAS_DX, int SCHED>
 __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     constexpr bool DX = VEL && HAS_DX;
     constexpr int WP = 3 * 4 * 64;
@@ -344,8 +359,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     constexpr int XBASE = 2 * WB;
     constexpr int NW_TOT = WB / 64, NX_TOT = XB / 64;            // 24 and 44 wave-instructions
     constexpr int NWS = (NW_TOT + 7) / 8;                        // weight slots per wave and stage
-    constexpr int NXS = (NX_TOT + 23) / 24;                      // activation slots per wave and stage (x3 per group)
-    static_assert(NWS + NXS <= 9, "more DMA slots per wave than MFMA pairs in one tap");
+    constexpr int XPARTS = SCHED == 0 ? 3 : 2;                   // stages of a group that issue activation DMA
+    constexpr int NXS = (NX_TOT + 8 * XPARTS - 1) / (8 * XPARTS);   // activation slots per wave in such a stage
+    static_assert(NWS + NXS <= 9 && NXS <= 4, "DMA slots per wave");
 
     f32x4* lds = lds_h3;
     const int tid = threadIdx.x;
@@ -361,16 +377,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
     const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS;
     const int nstage = 9 * a.nchunk;
-    const long HW = (long)a.H * a.W;
 
-    // ---- DMA slots.  Weights: instruction n = wave + 8t of every stage.  Activations: the 44 instructions of
-    // the NEXT (chunk,dz) patch are spread over the three dy stages of the current one: instruction
-    // n = dy*NXS*8 + t*8 + wave.  Per-lane source = patch-relative voxel (row*W + col) in plane pl; per patch a
+    // ---- DMA slots.  Weights: instruction n = wave + 8t of every stage.  Activations: the NX_TOT instructions of
+    // the NEXT (chunk,dz) patch are spread over XPARTS stages of the current one: instruction
+    // n = (p*NXS + t)*8 + wave.  Per-lane source = patch-relative voxel (row*W + col) in plane pl; per patch a
     // wave-uniform offset (chunk planes + patch origin) is added.
     const char* wsrc[NWS];
     int wdst[NWS];
-    const char* xsrc[3][NXS];
-    int xdst[3][NXS];
+    const char* xsrc[XPARTS][NXS];
+    int xdst[XPARTS][NXS];
+    int kx[XPARTS];                                              // activation instructions of this wave per part
 #pragma unroll
     for (int t = 0; t < NWS; ++t) {
         const int n = wave + 8 * t;
@@ -383,12 +399,14 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
         }
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < XPARTS; ++p) {
+        kx[p] = 0;
 #pragma unroll
         for (int t = 0; t < NXS; ++t) {
             const int n = (p * NXS + t) * 8 + wave;
             xsrc[p][t] = nullptr; xdst[p][t] = 0;
             if (n < NX_TOT) {
+                ++kx[p];
                 const int u = n * 64 + lane;
                 const bool tang = DX && u >= HP_XPP;
                 int uu = u - (tang ? HP_XPP : 0);
@@ -405,11 +423,26 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
         const int chunk = g / 3, dz = g - chunk * 3;
         return ((long)chunk * 4 * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
     };
+    // NBE_DBG builds only (timing experiments, results invalid): flags bit 8 = no weight DMA after the prologue,
+    // bit 9 = no activation DMA after the prologue, bit 10 / 11 = drop the third weight slot / the second activation slot
+    const bool dbg_now = NBE_DBG && (a.flags & 256), dbg_nox = NBE_DBG && (a.flags & 512);
+    const bool dbg_w2 = NBE_DBG && (a.flags & 1024), dbg_x1 = NBE_DBG && (a.flags & 2048);   // drop one slot each
+    bool dbg_pro = true;
     auto dma_w = [&](int t, int s) {
+        if (NBE_DBG && (dbg_now || (dbg_w2 && t == 2)) && !dbg_pro) return;
         if (wave + 8 * t < NW_TOT) dma16((const float*)(wsrc[t] + (long)s * WP * 16), lds + (s & 1) * WB + wdst[t]);
     };
     auto dma_x = [&](int p, int t, long xoff, int xb) {
+        if (NBE_DBG && (dbg_nox || (dbg_x1 && t == 1)) && !dbg_pro) return;
         if ((p * NXS + t) * 8 + wave < NX_TOT) dma16((const float*)(xsrc[p][t] + xoff), lds + XBASE + xb * XB + xdst[p][t]);
+    };
+    // wait until at most k of this wave's DMA instructions are outstanding (vmcnt counts in issue order)
+    auto wait_keep = [&](int k) {
+        if (k <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (k == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (k == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (k == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     };
 
     f32x16 ym[2], yc[2], dm[2], dc[2];
@@ -456,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     {
         const long x0off = patch_offset(0);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < XPARTS; ++p)
 #pragma unroll
             for (int t = 0; t < NXS; ++t) dma_x(p, t, x0off, 0);
 #pragma unroll
@@ -464,28 +497,30 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
         __syncthreads();
     }
 
+    dbg_pro = false;
     int g = 0, dy = 0;                                           // stage s = 3*g + dy
     for (int s = 0; s < nstage; ++s) {
         const bool pw = s + 1 < nstage, px = 3 * (g + 1) < nstage;
         const long xoff = px ? patch_offset(g + 1) : 0;
         const half8* wb = (const half8*)(lds + (s & 1) * WB);
         const half8* xb = (const half8*)(lds + XBASE + (g & 1) * XB);
+        const int nb = (g + 1) & 1;
         Ops o0, o1;
         load_ops(wb, xb, dy, 0, o0);
         load_ops(wb, xb, dy, 1, o1);
         __builtin_amdgcn_sched_barrier(0);
-        // first tap: one DMA instruction after every second MFMA -- W(s+1), then this stage's share of X(g+1)
+        // first tap: one DMA instruction after every second MFMA -- W(s+1) [SCHED 0: then a third of X(g+1)]
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             mfma1(o0, i);
             if (i & 1) {
                 const int t = i >> 1;
                 if (t < NWS) { if (pw) dma_w(t, s + 1); }
-                else if (t - NWS < NXS) {
+                else if (SCHED == 0 && t - NWS < NXS) {
                     if (px) {
-                        if (dy == 0) dma_x(0, t - NWS, xoff, (g + 1) & 1);
-                        else if (dy == 1) dma_x(1, t - NWS, xoff, (g + 1) & 1);
-                        else dma_x(2, t - NWS, xoff, (g + 1) & 1);
+                        if (dy == 0) dma_x(0, t - NWS, xoff, nb);
+                        else if (dy == 1) dma_x(1, t - NWS, xoff, nb);
+                        else dma_x(XPARTS - 1, t - NWS, xoff, nb);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -494,11 +529,28 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         load_ops(wb, xb, dy, 2, o0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_ops(o1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_ops(o0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                         // vmcnt(0): W(s+1) and this stage's X pieces landed
+        if (SCHED == 0) {
+            mfma_ops(o1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_ops(o0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                     // vmcnt(0): W(s+1) and this stage's X pieces landed
+        } else {
+            // second and third tap: this stage's half of X(g+1), one instruction every sixth MFMA
+            const bool xs = px && dy < 2;
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                if (i < 18) mfma1(o1, i); else mfma1(o0, i - 18);
+                if (i % 6 == 2 && i / 6 < NXS) {
+                    if (xs) { if (dy == 0) dma_x(0, i / 6, xoff, nb); else dma_x(XPARTS - 1, i / 6, xoff, nb); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // W(s+1) must have landed; the X pieces issued in this stage may stay in flight unless the group ends
+            wait_keep(xs ? (dy == 0 ? kx[0] : kx[XPARTS - 1]) : 0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if (++dy == 3) { dy = 0; ++g; }
     }
 
@@ -528,12 +580,12 @@ static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
 }
 
-template <bool VEL, bool HAS_DX>
+template <bool VEL, bool HAS_DX, int SCHED>
 static void launch_h3p_t(ConvKArgs ka, int ctiles, hipStream_t s) {
     constexpr int WB = 3 * 4 * 64 * (VEL ? 2 : 1), XB = HP_XPP * ((VEL && HAS_DX) ? 2 : 1);
     constexpr size_t smem = (size_t)(2 * WB + 2 * XB) * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
-    auto kern = conv_h3p_kernel<VEL, HAS_DX>;
+    auto kern = conv_h3p_kernel<VEL, HAS_DX, SCHED>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -551,8 +603,14 @@ void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_d
     static const int depth = (getenv("NBE_H3_DEPTH") && atoi(getenv("NBE_H3_DEPTH")) == 3) ? 3 : 2;
     static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
-        if (vel) { if (has_dx) launch_h3p_t<true, true>(ka, ct, s); else launch_h3p_t<true, false>(ka, ct, s); }
-        else launch_h3p_t<false, false>(ka, ct, s);
+        static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
+        if (sched == 0) {
+            if (vel) { if (has_dx) launch_h3p_t<true, true, 0>(ka, ct, s); else launch_h3p_t<true, false, 0>(ka, ct, s); }
+            else launch_h3p_t<false, false, 0>(ka, ct, s);
+        } else {
+            if (vel) { if (has_dx) launch_h3p_t<true, true, 1>(ka, ct, s); else launch_h3p_t<true, false, 1>(ka, ct, s); }
+            else launch_h3p_t<false, false, 1>(ka, ct, s);
+        }
         return;
     }
 #define NBE_DISPATCH_H3D(MODE, D)                                               \
