@@ -348,7 +348,10 @@ constexpr int HP_XPP = (HP_XP + 63) / 64 * 64;       // padded to whole wave-ins
 // Debug-build probes (NBE_BUILD_DBG=1, NBE_DEBUG_FLAGS): no DMA at all 482; weight DMA only 481; activation DMA
 // only 475; both 352 -- any mix of the two streams costs 20-30 % whatever its size (2W+1X slots: 394, 3W+1X: 385,
 // 2W+2X: 387), and neither de-bursting (SCHED 1), nor leaving the DMA in flight across the barrier, nor a deeper
-// ring, nor 40 % fewer bytes (this kernel vs the flat one) changes that.  Unexplained; default stays SCHED 0.
+// ring, nor 40 % fewer bytes (this kernel vs the flat one) changes that.  Explanation (profiles/
+// r01_clock_vs_dma_conv_h3p.txt): in CYCLES all variants are the same kernel (matrix pipe busy 64.6-66.1 % of SIMD
+// cycles); the chip holds 2.35-2.38 GHz without the combined DMA streams and 1.81 GHz with them.  The kernel is
+// power-limited, so what pays is less energy per MFMA (bytes, LDS reads), not a tighter issue stream.
 template <bool VEL, bool HAS_DX, int SCHED>
 __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     constexpr bool DX = VEL && HAS_DX;
