@@ -5,7 +5,11 @@
 // (hi = f16(x), lo = f16((x - hi) * 2^11)) and one float32 product becomes three f16 MFMAs with float32
 // accumulation,   a*b  ~=  a_hi*b_hi  +  2^-11 * (a_hi*b_lo + a_lo*b_hi),
 // i.e. 22 significant bits per operand.  v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32 MFMA, so the
-// 3-term split is ~5.3x the strict-float32 matrix rate.  Measured accuracy: tests/test_gpu_h3.py.
+// 3-term split is ~5.3x the strict-float32 matrix rate.  Accuracy is held to the float32 tolerances by the GPU
+// tests, which are parametrised over both precisions (tests/test_gpu_layers.py, test_gpu_model.py, test_gpu_api.py).
+//
+// Two convolution kernels: conv_h3p_kernel (2-D patches, the 3x3x3 layers = 98 % of the FLOPs) and
+// conv_h3_kernel (flat positions: 1x1x1 skips, up-sample parities, stride-2 down-sample; 3x3x3 only for A/B).
 //
 // Storage: plane 2g holds hi, plane 2g+1 holds lo of channels 8g..8g+7 (8 x f16 = 16 B per voxel): one
 // 16-byte unit is exactly the A/B operand of one lane for one MFMA (k = 8*(lane>>5) + j).
@@ -85,15 +89,13 @@ __device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int
 // Workgroup: 512 threads = 8 waves; tile = 64 output channels x 256 flat positions.
 // wave w: it = w & 1 (32 couts), jq = w >> 1 (64 positions = 2 MFMA column tiles).
 //
-// Pipeline: activation row segments live in a 3-deep LDS ring, weights in a 2-deep one.  During stage s
-// the DMA of W(s+1) and X(s+2) is issued BETWEEN the MFMAs of the first tap; at the end of the stage a
-// counted s_waitcnt leaves this wave's X(s+2) pieces in flight (vmcnt counts in issue order: X(s+1), issued
-// a whole stage earlier, and W(s+1) are complete), then a raw s_barrier.  Two stages of activation traffic
-// are therefore in flight at any time and the L2->LDS latency (~1.5 us per 64 KB) is off the critical path.
-// Depth of the activation ring.  Measured on MI355X (512^3 bench): depth 2 (one stage of DMA in flight) 368
-// TFLOP/s-equivalent, depth 3 (two stages in flight, counted vmcnt) 340: the kernel is limited by L2->LDS
-// throughput, not latency, so the deeper ring only adds LDS pressure.  Template parameter XDEPTH; the launcher
-// picks it from the environment variable NBE_H3_DEPTH (default 2) so both can be timed on one device.
+// Pipeline: weights live in a 2-deep LDS ring, activation row segments in a ring of XDEPTH (2 or 3) stages.
+// During stage s the DMA of W(s+1) and X(s+XDEPTH-1) is issued BETWEEN the MFMAs of the first tap.
+//   XDEPTH 2 (default): every stage ends with vmcnt(0) + barrier, one stage of DMA in flight.
+//   XDEPTH 3: a counted s_waitcnt leaves this wave's X(s+2) pieces in flight across a raw s_barrier (vmcnt
+//             counts in issue order: X(s+1), issued a whole stage earlier, and W(s+1) are complete).
+// Same-device A/B (env NBE_H3_DEPTH): depth 2 = 343, depth 3 = 332 TFLOP/s-equivalent on the 512^3 bench --
+// DMA latency is not what limits these kernels (see the power note at conv_h3p_kernel).
 
 template <int MODE>
 struct H3Geom {

@@ -19,7 +19,7 @@ Z, OM = 0.5, 0.3
 
 
 def _synthetic(seed, mid):
-    # same generator as oracle/params.py:synthetic_params (kept in step by test_golden_inputs_reproducible)
+    # the generator the golden fixtures were made with (tests/golden/make_golden.py)
     from oracle import params as P
     return P.synthetic_params(seed=seed, mid_chan=mid)
 
