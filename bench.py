@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--max-tile", type=int, default=256,
                     help="internal tile edge: sub-boxes are merged into tiles up to this size when that is exact "
                          "(crop %% 8 == 0); 0 = run the caller's 64 sub-boxes of 224^3 one by one")
-    ap.add_argument("--precision", default=os.environ.get("NBE_PRECISION", "f16x3"), choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default=os.environ.get("NBE_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16"],
                     help="f16x3 (default): float32-equivalent split-f16 MFMA, 3 MFMAs per product, f32 accumulate, "
                          "whole-network error vs the float64 oracle equal to or below the strict path's; "
                          "f32: strict float32 MFMA")
@@ -156,7 +156,7 @@ def main():
         dom = max(prof, key=lambda e: e["ms"])
         tot_ms = sum(e["ms"] for e in prof)
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0, "f16": PEAK_F16_MFMA_TFLOPS}[precision]
         # HBM-side bytes per launch of the dominant kernel cannot be read from inside the process; they come from
         # the committed rocprofv3 --pmc passes of this exact workload (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # profiles/r01_pmc_fetch_write_default_f16x3.txt) and are reported only when the configuration matches.
@@ -175,7 +175,8 @@ def main():
 
     if rank == 0:
         vox = float(N) ** 3
-        dtype = {"f32": "f32", "f16x3": "f32-equivalent: f16x3 split MFMA (3 f16 MFMAs per product, f32 accumulate)"}
+        dtype = {"f32": "f32", "f16x3": "f32-equivalent: f16x3 split MFMA (3 f16 MFMAs per product, f32 accumulate)",
+                 "f16": "f16 (f16 operands and activations, f32 accumulate; the reference's dtype=float16 rows)"}
         out = {
             "metric": "voxels/sec (disp+vel) on 512^3 box, ndiv=4" if vel else "voxels/sec (disp only)",
             "value": vox * args.steps / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,

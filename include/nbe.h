@@ -48,8 +48,12 @@ int nbe_version(void);
  * replaces: the implicit JAX device/jit state created by SubboxProcessor.__init__ (subbox.py:106-137) */
 int nbe_create(int device_id, nbe_ctx** out);
 int nbe_destroy(nbe_ctx* ctx);
-/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own stream */
+/* run on a caller-provided hipStream_t (e.g. torch's current stream) so that the caller's device work before
+ * and after a call is ordered with it; NULL = the device's default (null) stream, as everywhere in HIP.
+ * A new context runs on its own non-blocking stream (NOT ordered with the null stream); nbe_use_own_stream
+ * returns to it.  Both synchronise the stream being left. */
 int nbe_set_stream(nbe_ctx* ctx, void* hip_stream);
+int nbe_use_own_stream(nbe_ctx* ctx);
 int nbe_synchronize(nbe_ctx* ctx);
 
 /* model hyper-parameters: StyleNBodyEmulatorVelCore(style_size=2, in_chan, out_chan, mid_chan, eps)
@@ -61,8 +65,10 @@ int nbe_set_arch(nbe_ctx* ctx, int in_chan, int out_chan, int mid_chan, float ep
  * of x (SubboxConfig.dtype, style_layers_vel.py:103-105); its float32 runs on TF32-class tensor cores.
  *   NBE_PREC_F32    strict float32 MFMA (default)
  *   NBE_PREC_F16X3  float32-equivalent: operands split into two f16 numbers, three f16 MFMAs per product,
- *                   float32 accumulation (22-bit operands; measured whole-network error equal to float32's) */
-enum { NBE_PREC_F32 = 0, NBE_PREC_F16X3 = 1 };
+ *                   float32 accumulation (22-bit operands; measured whole-network error equal to float32's)
+ *   NBE_PREC_F16    plain float16 operands, one f16 MFMA per product, float32 accumulation: the arithmetic of
+ *                   the reference's SubboxConfig.dtype = float16 configuration (its fastest rows, README.md:245-250) */
+enum { NBE_PREC_F32 = 0, NBE_PREC_F16X3 = 1, NBE_PREC_F16 = 2 };
 int nbe_set_precision(nbe_ctx* ctx, int precision);
 
 /* replaces model.apply's `params` argument for the Style* cores (README.md:155; subbox.py:224-233) */

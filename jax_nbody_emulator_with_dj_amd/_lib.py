@@ -38,6 +38,7 @@ SIGNATURES = {
     "nbe_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "nbe_destroy": (C.c_int, [C.c_void_p]),
     "nbe_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nbe_use_own_stream": (C.c_int, [C.c_void_p]),
     "nbe_synchronize": (C.c_int, [C.c_void_p]),
     "nbe_set_arch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     "nbe_load_style_weights": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), C.c_int]),

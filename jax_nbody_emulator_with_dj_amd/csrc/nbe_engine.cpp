@@ -142,7 +142,8 @@ extern "C" double nbe_vel_norm(double z, double Om) {
 // helpers
 // ------------------------------------------------------------------------------------------------
 static int roundup(int v, int m) { return (v + m - 1) / m * m; }
-static int planes_for(int C) { return roundup(C, 16) / 4; }     // every consumer reads whole 16-channel chunks at most
+// every consumer reads whole 16-channel chunks; PREC_F16 stores 8 channels per plane, the others 4 (or hi+lo of 8)
+static int planes_for(int C, int prec) { return roundup(C, 16) / (prec == PREC_F16 ? 8 : 4); }
 
 static bool is_device_ptr(const void* p) {
     hipPointerAttribute_t at;
@@ -170,7 +171,7 @@ static Planes ws_planes(nbe_ctx* c, int G, int D, int H, int W, int64_t* off_out
 struct Tensor { Planes p; int64_t off = -1; };
 static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
     Tensor t;
-    t.p = ws_planes(c, planes_for(C), D, H, W, &t.off);
+    t.p = ws_planes(c, planes_for(C, c->prec), D, H, W, &t.off);
     return t;
 }
 static void tfree(nbe_ctx* c, Tensor& t) { if (t.off >= 0) c->arena.release(t.off); t.off = -1; }
@@ -199,8 +200,8 @@ static void prof_collect(nbe_ctx* c) {
 static std::string conv_name(const PackedW& pw, bool vel, bool has_dx) {
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
     char b[96];
-    if (pw.prec == PREC_F16X3)
-        snprintf(b, sizeof b, "conv_h3<%s,%s,%s>", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx");
+    if (prec_is_half(pw.prec))
+        snprintf(b, sizeof b, "%s<%s,%s,%s>", pw.prec == PREC_F16 ? "conv_h1" : "conv_h3", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx");
     else
         snprintf(b, sizeof b, "conv_mfma<%s,%s,%s,ni%d>", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx", pw.ni);
     return b;
@@ -290,7 +291,7 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
         return fail("internal: concat geometry mismatch in %s", name);
     for (int p = 0; p < 8; ++p) {
         ConvLaunch cl; cl.in = x.p; cl.Dv = x.p.D; cl.Hv = x.p.H; cl.Wv = x.p.W; cl.out = cat.p;
-        cl.out_g0 = c->mid / 4; cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
+        cl.out_g0 = c->mid / (c->prec == PREC_F16 ? 8 : 4); cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
         cl.flags = F_ACT; cl.set = p;
         run_conv(c, *L, cl, true);
     }
@@ -299,7 +300,7 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
 
 static void crop_into(nbe_ctx* c, const Tensor& src, int crop, const Tensor& cat) {
     if (c->dry) return;
-    Planes s = src.p; s.G = c->mid / 4;
+    Planes s = src.p; s.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
     launch_crop(s, crop, cat.p, 0, c->vel, c->stream);
 }
 
@@ -463,12 +464,12 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
         PackedW& pw = L.pw;
         pw.mode = L.kind == 0 ? MODE_FLAT3 : (L.kind == 2 ? MODE_DOWN : MODE_FLAT1);
         pw.prec = c->prec;
-        pw.ni = (c->prec == PREC_F16X3 || d.cout > 32) ? 2 : 1;
+        pw.ni = (prec_is_half(c->prec) || d.cout > 32) ? 2 : 1;
         pw.cin = d.cin; pw.cout = d.cout;
         pw.cin_pad = roundup(d.cin, prec_ck(c->prec, pw.mode));
         pw.ctiles = (d.cout + 32 * pw.ni - 1) / (32 * pw.ni);
         pw.nsets = L.kind == 3 ? 8 : 1;
-        pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad;
+        pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad / (c->prec == PREC_F16 ? 2 : 1);
         HIPCHK(hipMalloc((void**)&pw.w, pw.floats * pw.nsets * 4));
         if (c->vel) HIPCHK(hipMalloc((void**)&pw.dw, pw.floats * pw.nsets * 4));
         const int nb = pw.ctiles * 32 * pw.ni;
@@ -551,7 +552,14 @@ int nbe_destroy(nbe_ctx* c) {
 int nbe_set_stream(nbe_ctx* c, void* s) {
     if (!c) return fail("null context");
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;      // NULL is the device's default (null) stream, as everywhere in HIP
+    return 0;
+}
+
+int nbe_use_own_stream(nbe_ctx* c) {
+    if (!c) return fail("null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return 0;
 }
 
@@ -662,7 +670,7 @@ int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int
 
 int nbe_set_precision(nbe_ctx* c, int prec) {
     if (!c) return fail("null context");
-    if (prec != PREC_F32 && prec != PREC_F16X3) return fail("precision must be NBE_PREC_F32 (0) or NBE_PREC_F16X3 (1)");
+    if (prec != PREC_F32 && prec != PREC_F16X3 && prec != PREC_F16) return fail("precision must be NBE_PREC_F32 (0), NBE_PREC_F16X3 (1) or NBE_PREC_F16 (2)");
     if (c->have_weights && prec != c->prec)
         return fail("nbe_set_precision must be called before the weights are loaded (they are packed per precision)");
     c->prec = prec;
@@ -818,11 +826,11 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         PackedW& pw = L.pw;
         pw.mode = kind == 0 ? MODE_FLAT3 : (kind == 2 ? MODE_DOWN : MODE_FLAT1);
         pw.prec = c->prec;
-        pw.ni = (c->prec == PREC_F16X3 || cout > 32) ? 2 : 1; pw.cin = cin; pw.cout = cout;
+        pw.ni = (prec_is_half(c->prec) || cout > 32) ? 2 : 1; pw.cin = cin; pw.cout = cout;
         pw.cin_pad = roundup(cin, prec_ck(c->prec, pw.mode));
         pw.ctiles = (cout + 32 * pw.ni - 1) / (32 * pw.ni);
         pw.nsets = kind == 3 ? 8 : 1;
-        pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad;
+        pw.floats = (int64_t)pw.ctiles * 32 * pw.ni * mode_nseg(pw.mode) * mode_taps(pw.mode) * pw.cin_pad / (c->prec == PREC_F16 ? 2 : 1);
 #define TCHK(e) if ((e) != hipSuccess) { rc = fail("hip error in nbe_test_layer: %s", hipGetErrorString(hipGetLastError())); break; }
         TCHK(hipMalloc((void**)&pw.w, pw.floats * pw.nsets * 4));
         if (vel) TCHK(hipMalloc((void**)&pw.dw, pw.floats * pw.nsets * 4));
@@ -838,7 +846,7 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         TCHK(hipMalloc((void**)&dout, nout * 4));
         // private workspace: input, output, residual planes
         auto mk = [&](int C, int d, int h, int wd, int64_t* bytes) {
-            Planes p; p.G = planes_for(C); p.D = d; p.H = h; p.W = wd; p.pstride = (p.vox() + 63) & ~int64_t(63);
+            Planes p; p.G = planes_for(C, c->prec); p.D = d; p.H = h; p.W = wd; p.pstride = (p.vox() + 63) & ~int64_t(63);
             *bytes = (int64_t)p.G * p.pstride * 16; return p; };
         int64_t bi, bo;
         Planes pin = mk(cin, D, H, W, &bi), pout = mk(cout, OD, OH, OW, &bo), pres = pout;

@@ -26,7 +26,12 @@ struct Planes {
 //               accumulation (22 significant bits per operand; the dropped lo*lo term is 2^-22 relative).
 //               Planes hold 8 x f16 per voxel: plane 2g = hi, 2g+1 = lo of channels 8g..8g+7 -- the same
 //               bytes and plane count as PREC_F32, so workspace planning is identical.
-enum Precision { PREC_F32 = 0, PREC_F16X3 = 1 };
+//   PREC_F16    plain float16 operands, one f16 MFMA per product, float32 accumulation: what the reference
+//               computes with SubboxConfig.dtype = float16.  Planes hold 8 x f16 per voxel, plane g = channels
+//               8g..8g+7 (half the bytes and planes of the other two).
+enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
+inline constexpr bool prec_is_half(int prec) { return prec == PREC_F16X3 || prec == PREC_F16; }
+inline constexpr int prec_parts(int prec) { return prec == PREC_F16X3 ? 2 : 1; }
 constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
 
 enum ConvMode { MODE_FLAT3 = 0, MODE_FLAT1 = 1, MODE_DOWN = 2 };
@@ -37,7 +42,7 @@ constexpr int TILE_VOX = 256;                 // voxels per workgroup tile
 inline constexpr int mode_taps(int mode) { return mode == MODE_FLAT3 ? 3 : 1; }
 inline constexpr int mode_nseg(int mode) { return mode == MODE_FLAT3 ? 9 : (mode == MODE_DOWN ? 8 : 1); }
 inline constexpr int mode_ck(int mode) { return mode == MODE_FLAT3 ? 8 : 16; }
-inline constexpr int prec_ck(int prec, int mode) { return prec == PREC_F16X3 ? 16 : mode_ck(mode); }
+inline constexpr int prec_ck(int prec, int mode) { return prec_is_half(prec) ? 16 : mode_ck(mode); }
 
 // One packed weight set (see pack_index in nbe_kernels.hip for the layout).
 struct PackedW {

@@ -233,10 +233,10 @@ void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, 
     ka.w = pw.w + (size_t)L.set * pw.floats;
     ka.dw = pw.dw ? pw.dw + (size_t)L.set * pw.floats : nullptr;
     ka.nchunk = pw.cin_pad / prec_ck(pw.prec, pw.mode);
-    ka.cout_groups = pw.prec == PREC_F16X3 ? (pw.cout + 7) / 8 : (pw.cout + 3) / 4;
+    ka.cout_groups = prec_is_half(pw.prec) ? (pw.cout + 7) / 8 : (pw.cout + 3) / 4;
     ka.flags = L.flags;
     ka.ntiles = (int)((ka.Q + TILE_VOX - 1) / TILE_VOX);
-    if (pw.prec == PREC_F16X3) { launch_conv_h3(pw, ka, vel, has_dx, s); return; }
+    if (prec_is_half(pw.prec)) { launch_conv_h3(pw, ka, vel, has_dx, s); return; }
     const int ct = pw.ctiles;
 #define NBE_DISPATCH(MODE)                                                                   \
     if (vel) {                                                                               \
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
 }
 
 void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s) {
-    if (pw.prec == PREC_F16X3) { launch_pack_h3(w_oidhw, cout, cin, kind, pw, dst, s); return; }
+    if (prec_is_half(pw.prec)) { launch_pack_h3(w_oidhw, cout, cin, kind, pw, dst, s); return; }
     const long total = pw.floats * pw.nsets;
     const int nchunk = pw.cin_pad / mode_ck(pw.mode);
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
@@ -383,14 +383,14 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ b
 
 void launch_gather(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
                    const Planes& dst, float scale, int prec, hipStream_t s) {
-    if (prec == PREC_F16X3) { launch_gather_h8(box, C, Db, Hb, Wb, a0, a1, a2, dst.x, dst, scale, s); return; }
+    if (prec_is_half(prec)) { launch_gather_h8(box, C, Db, Hb, Wb, a0, a1, a2, dst.x, dst, scale, prec_parts(prec), s); return; }
     const long V = dst.vox();
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, box, C, Db, Hb, Wb,
                        a0, a1, a2, dst.x, dst.pstride, dst.G, dst.D, dst.H, dst.W, scale);
 }
 
 void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, int prec, hipStream_t s) {
-    if (prec == PREC_F16X3) { launch_gather_h8(src, C, dst.D, dst.H, dst.W, 0, 0, 0, tangent ? dst.dx : dst.x, dst, scale, s); return; }
+    if (prec_is_half(prec)) { launch_gather_h8(src, C, dst.D, dst.H, dst.W, 0, 0, 0, tangent ? dst.dx : dst.x, dst, scale, prec_parts(prec), s); return; }
     // a dense (C,D,H,W) array is a "box" of the same size gathered at origin 0
     const long V = dst.vox();
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, src, C, dst.D, dst.H,
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const float* __restric
 }
 
 void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, int prec, hipStream_t s) {
-    if (prec == PREC_F16X3) { launch_from_planes_h8(tangent ? src.dx : src.x, src, C, dst, s); return; }
+    if (prec_is_half(prec)) { launch_from_planes_h8(tangent ? src.dx : src.x, src, C, dst, prec_parts(prec), s); return; }
     const long V = src.vox();
     hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s,
                        tangent ? src.dx : src.x, src.pstride, V, C, dst);
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, 
 void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
                  int prec, hipStream_t s) {
-    if (prec == PREC_F16X3) { launch_head_h8(y, xin, c0, C, Dz, vel_fac, vel, disp, velo, out_dtype, Db, Hb, Wb, a0, a1, a2, s); return; }
+    if (prec_is_half(prec)) { launch_head_h8(y, xin, c0, C, Dz, vel_fac, vel, disp, velo, out_dtype, Db, Hb, Wb, a0, a1, a2, prec_parts(prec), s); return; }
     const long V = y.vox();
     const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
     dim3 grid((unsigned)((V + 255) / 256)), block(256);

@@ -42,9 +42,10 @@ __device__ __forceinline__ f32x4 join4(const half4 hi, const half4 lo) {
 // Epilogue of one 32x32 accumulator tile for output voxel `o` (this lane's column): join main + correction,
 // bias, residual, LeakyReLU (+ tangent) in float32, then split to hi/lo and store 4 channels (8 B) per part.
 // it = cout half of the wave, lh = lane half; register 4k+e of the tile is cout 32*it + 8k + 4*lh + e.
-template <bool VEL>
+template <bool VEL, bool SPLIT>
 __device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int lh, long o, const f32x16& ym,
                                          const f32x16& yc, const f32x16& dm, const f32x16& dc) {
+    constexpr int PARTS = SPLIT ? 2 : 1;
     const bool act = a.flags & F_ACT, res = a.flags & F_RES;
     char* const yb = (char*)a.y;
     char* const dyb = (char*)a.dy;
@@ -56,14 +57,25 @@ __device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int
         f32x4 v, dv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = ym[4 * k + e] + yc[4 * k + e] * H3_INV + bv[e];
-            dv[e] = dm[4 * k + e] + dc[4 * k + e] * H3_INV;
+            v[e] = ym[4 * k + e] + (SPLIT ? yc[4 * k + e] * H3_INV : 0.f) + bv[e];
+            dv[e] = dm[4 * k + e] + (SPLIT ? dc[4 * k + e] * H3_INV : 0.f);
         }
         if (res) {
-            const long rb = ((long)(2 * unit) * a.res_pstride + o) * 16 + 8 * lh;
+            const long rb = ((long)(PARTS * unit) * a.res_pstride + o) * 16 + 8 * lh;
             const long rl = rb + a.res_pstride * 16;
-            v += join4(*(const half4*)((const char*)a.r + rb), *(const half4*)((const char*)a.r + rl));
-            if (VEL) dv += join4(*(const half4*)((const char*)a.dr + rb), *(const half4*)((const char*)a.dr + rl));
+            if (SPLIT) {
+                v += join4(*(const half4*)((const char*)a.r + rb), *(const half4*)((const char*)a.r + rl));
+                if (VEL) dv += join4(*(const half4*)((const char*)a.dr + rb), *(const half4*)((const char*)a.dr + rl));
+            } else {
+                const half4 rh = *(const half4*)((const char*)a.r + rb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rh[e];
+                if (VEL) {
+                    const half4 dh = *(const half4*)((const char*)a.dr + rb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += (float)dh[e];
+                }
+            }
         }
         if (act) {
 #pragma unroll
@@ -72,16 +84,16 @@ __device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int
                 v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
             }
         }
-        const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + o) * 16 + 8 * lh;
+        const long ob = ((long)(a.out_g0 + PARTS * unit) * a.out_pstride + o) * 16 + 8 * lh;
         const long ol = ob + a.out_pstride * 16;
         half4 hi, lo;
         split4(v, hi, lo);
         *(half4*)(yb + ob) = hi;
-        *(half4*)(yb + ol) = lo;
+        if (SPLIT) *(half4*)(yb + ol) = lo;
         if (VEL) {
             split4(dv, hi, lo);
             *(half4*)(dyb + ob) = hi;
-            *(half4*)(dyb + ol) = lo;
+            if (SPLIT) *(half4*)(dyb + ol) = lo;
         }
     }
 }
@@ -97,18 +109,22 @@ __device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int
 // Same-device A/B (env NBE_H3_DEPTH): depth 2 = 343, depth 3 = 332 TFLOP/s-equivalent on the 512^3 bench --
 // DMA latency is not what limits these kernels (see the power note at conv_h3p_kernel).
 
-template <int MODE>
+// SPLIT = true: f16x3 (hi and lo planes, three MFMAs per product); SPLIT = false: plain f16 (PREC_F16: hi planes
+// only, one MFMA per product -- the arithmetic of the reference's dtype=float16 configuration).
+// A 16-channel chunk is UN = 2*PARTS units of 8 channels: unit = PARTS*h + part (h = MFMA lane half, part 0 = hi).
+template <int MODE, bool SPLIT>
 struct H3Geom {
+    static constexpr int PARTS = SPLIT ? 2 : 1, UN = 2 * PARTS;
     static constexpr int TAPS = mode_taps(MODE);
     static constexpr int XV = (MODE == MODE_FLAT3) ? 288 : 256;   // 256 + 2 halo voxels, rounded to 32
-    static constexpr int WP = TAPS * 4 * 64;                      // 16-byte units: weights of one stage
-    static constexpr int XP = 4 * XV;                             // 16-byte units: activations of one stage
+    static constexpr int WP = TAPS * UN * 64;                     // 16-byte units: weights of one stage
+    static constexpr int XP = UN * XV;                            // 16-byte units: activations of one stage
 };
 
-template <int MODE, bool VEL, bool HAS_DX, int H3_XDEPTH>
+template <int MODE, bool VEL, bool HAS_DX, int H3_XDEPTH, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
-    typedef H3Geom<MODE> G;
-    constexpr int TAPS = G::TAPS, XV = G::XV, WP = G::WP, XP = G::XP;
+    typedef H3Geom<MODE, SPLIT> G;
+    constexpr int TAPS = G::TAPS, XV = G::XV, WP = G::WP, XP = G::XP, PARTS = G::PARTS, UN = G::UN;
     constexpr bool DX = VEL && HAS_DX;
     constexpr int WB = WP * (VEL ? 2 : 1);           // one weight buffer  (W [, dW])
     constexpr int XB = XP * (DX ? 2 : 1);            // one activation buffer (X [, dX])
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
         if (MODE == MODE_FLAT3) segoff = (seg / 3) * HW + (seg % 3) * a.W;
         else if (MODE == MODE_DOWN) segoff = (seg >> 2) * HW + ((seg >> 1) & 1) * a.W + (seg & 1);
         else segoff = 0;
-        return ((long)chunk * 4 * a.in_pstride + segoff) * 16;
+        return ((long)chunk * UN * a.in_pstride + segoff) * 16;
     };
     auto dma_w = [&](int t, int s) {                 // weights of stage s -> weight buffer s & 1
         if (wave + 8 * t < NW_TOT) dma16((const float*)(wsrc[t] + (long)s * WP * 16), lds + (s & 1) * WB + wdst[t]);
@@ -217,31 +233,33 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
     // operands of one dx tap
     struct Ops { half8 wh, wl, dwh, dwl, xh[2], xl[2], dxh[2], dxl[2]; };
     auto load_ops = [&](const half8* wb, const half8* xb, int tap, Ops& o) {
-        const int wo = (tap * 4 + 2 * lh) * 64 + 32 * it + li;
-        o.wh = wb[wo]; o.wl = wb[wo + 64];
-        if (VEL) { o.dwh = wb[OFF_DW + wo]; o.dwl = wb[OFF_DW + wo + 64]; }
+        const int wo = (tap * UN + PARTS * lh) * 64 + 32 * it + li;
+        o.wh = wb[wo];
+        if (SPLIT) o.wl = wb[wo + 64];
+        if (VEL) { o.dwh = wb[OFF_DW + wo]; if (SPLIT) o.dwl = wb[OFF_DW + wo + 64]; }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-            const int xo = (2 * lh) * XV + jq * 64 + 32 * jt + li + (MODE == MODE_FLAT3 ? tap : 0);
-            o.xh[jt] = xb[xo]; o.xl[jt] = xb[xo + XV];
-            if (DX) { o.dxh[jt] = xb[OFF_DXX + xo]; o.dxl[jt] = xb[OFF_DXX + xo + XV]; }
+            const int xo = (PARTS * lh) * XV + jq * 64 + 32 * jt + li + (MODE == MODE_FLAT3 ? tap : 0);
+            o.xh[jt] = xb[xo];
+            if (SPLIT) o.xl[jt] = xb[xo + XV];
+            if (DX) { o.dxh[jt] = xb[OFF_DXX + xo]; if (SPLIT) o.dxl[jt] = xb[OFF_DXX + xo + XV]; }
         }
     };
     // the i-th of the 18 MFMAs of one tap (i is a compile-time constant after unrolling): jt = i / 9
     auto mfma1 = [&](const Ops& o, int i) {
         const int jt = i / 9, k = i % 9;
         if (k == 0) ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xh[jt], ym[jt], 0, 0, 0);
-        if (k == 1) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xl[jt], yc[jt], 0, 0, 0);
-        if (k == 2) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.xh[jt], yc[jt], 0, 0, 0);
+        if (SPLIT && k == 1) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xl[jt], yc[jt], 0, 0, 0);
+        if (SPLIT && k == 2) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.xh[jt], yc[jt], 0, 0, 0);
         if (VEL) {
             if (k == 3) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xh[jt], dm[jt], 0, 0, 0);
-            if (k == 4) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xl[jt], dc[jt], 0, 0, 0);
-            if (k == 5) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwl, o.xh[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 4) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xl[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 5) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwl, o.xh[jt], dc[jt], 0, 0, 0);
         }
         if (DX) {
             if (k == 6) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxh[jt], dm[jt], 0, 0, 0);
-            if (k == 7) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxl[jt], dc[jt], 0, 0, 0);
-            if (k == 8) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.dxh[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 7) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxl[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 8) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.dxh[jt], dc[jt], 0, 0, 0);
         }
     };
     auto mfma_ops = [&](const Ops& o) {
@@ -319,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
             o = ((long)(z * a.osz + a.oz) * a.Ho + (yy * a.osz + a.oy)) * a.Wo + (xx * a.osz + a.ox);
         }
         if (!valid) continue;
-        h3_store<VEL>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
+        h3_store<VEL, SPLIT>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
     }
 }
 
@@ -337,8 +355,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
 constexpr int HP_ROWS = 8, HP_COLS = 32;
 constexpr int HP_RS = HP_COLS + 2;                   // LDS row stride (units)
 constexpr int HP_PL = (HP_ROWS + 2) * HP_RS;         // units per plane of the patch image: 340
-constexpr int HP_XP = 4 * HP_PL;                     // valid units of one tensor's patch (4 planes): 1360
-constexpr int HP_XPP = (HP_XP + 63) / 64 * 64;       // padded to whole wave-instructions: 1408
 
 // SCHED selects how the DMA of one stage is issued (A/B on one device: env NBE_H3_SCHED):
 //   0  burst: W(s+1) and a third of X(g+1) right after the barrier, interleaved with the first tap's MFMAs;
@@ -354,10 +370,13 @@ constexpr int HP_XPP = (HP_XP + 63) / 64 * 64;       // padded to whole wave-ins
 // r01_clock_vs_dma_conv_h3p.txt): in CYCLES all variants are the same kernel (matrix pipe busy 64.6-66.1 % of SIMD
 // cycles); the chip holds 2.35-2.38 GHz without the combined DMA streams and 1.81 GHz with them.  The kernel is
 // power-limited, so what pays is less energy per MFMA (bytes, LDS reads), not a tighter issue stream.
-template <bool VEL, bool HAS_DX, int SCHED>
+template <bool VEL, bool HAS_DX, int SCHED, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     constexpr bool DX = VEL && HAS_DX;
-    constexpr int WP = 3 * 4 * 64;
+    constexpr int PARTS = SPLIT ? 2 : 1, UN = 2 * PARTS;         // units of 8 channels per 16-channel chunk
+    constexpr int HP_XP = UN * HP_PL;                            // valid units of one tensor's patch: 1360 (680)
+    constexpr int HP_XPP = (HP_XP + 63) / 64 * 64;               // padded to whole wave-instructions: 1408 (704)
+    constexpr int WP = 3 * UN * 64;
     constexpr int WB = WP * (VEL ? 2 : 1);
     constexpr int XB = HP_XPP * (DX ? 2 : 1);
     constexpr int OFF_DW = WP, OFF_DXX = HP_XPP;
@@ -426,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     }
     auto patch_offset = [&](int g) -> long {                     // g = chunk*3 + dz
         const int chunk = g / 3, dz = g - chunk * 3;
-        return ((long)chunk * 4 * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
+        return ((long)chunk * UN * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
     };
     // NBE_DBG builds only (timing experiments, results invalid): flags bit 8 = no weight DMA after the prologue,
     // bit 9 = no activation DMA after the prologue, bit 10 / 11 = drop the third weight slot / the second activation slot
@@ -459,30 +478,32 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     struct Ops { half8 wh, wl, dwh, dwl, xh[2], xl[2], dxh[2], dxl[2]; };
     // operands of tap (dy, dx): weights of the current stage, activations from the resident patch
     auto load_ops = [&](const half8* wb, const half8* xb, int dy, int dx, Ops& o) {
-        const int wo = (dx * 4 + 2 * lh) * 64 + 32 * it + li;
-        o.wh = wb[wo]; o.wl = wb[wo + 64];
-        if (VEL) { o.dwh = wb[OFF_DW + wo]; o.dwl = wb[OFF_DW + wo + 64]; }
+        const int wo = (dx * UN + PARTS * lh) * 64 + 32 * it + li;
+        o.wh = wb[wo];
+        if (SPLIT) o.wl = wb[wo + 64];
+        if (VEL) { o.dwh = wb[OFF_DW + wo]; if (SPLIT) o.dwl = wb[OFF_DW + wo + 64]; }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-            const int xo = (2 * lh) * HP_PL + (2 * jq + jt + dy) * HP_RS + li + dx;
-            o.xh[jt] = xb[xo]; o.xl[jt] = xb[xo + HP_PL];
-            if (DX) { o.dxh[jt] = xb[OFF_DXX + xo]; o.dxl[jt] = xb[OFF_DXX + xo + HP_PL]; }
+            const int xo = (PARTS * lh) * HP_PL + (2 * jq + jt + dy) * HP_RS + li + dx;
+            o.xh[jt] = xb[xo];
+            if (SPLIT) o.xl[jt] = xb[xo + HP_PL];
+            if (DX) { o.dxh[jt] = xb[OFF_DXX + xo]; if (SPLIT) o.dxl[jt] = xb[OFF_DXX + xo + HP_PL]; }
         }
     };
     auto mfma1 = [&](const Ops& o, int i) {
         const int jt = i / 9, k = i % 9;
         if (k == 0) ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xh[jt], ym[jt], 0, 0, 0);
-        if (k == 1) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xl[jt], yc[jt], 0, 0, 0);
-        if (k == 2) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.xh[jt], yc[jt], 0, 0, 0);
+        if (SPLIT && k == 1) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.xl[jt], yc[jt], 0, 0, 0);
+        if (SPLIT && k == 2) yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.xh[jt], yc[jt], 0, 0, 0);
         if (VEL) {
             if (k == 3) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xh[jt], dm[jt], 0, 0, 0);
-            if (k == 4) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xl[jt], dc[jt], 0, 0, 0);
-            if (k == 5) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwl, o.xh[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 4) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwh, o.xl[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 5) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.dwl, o.xh[jt], dc[jt], 0, 0, 0);
         }
         if (DX) {
             if (k == 6) dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxh[jt], dm[jt], 0, 0, 0);
-            if (k == 7) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxl[jt], dc[jt], 0, 0, 0);
-            if (k == 8) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.dxh[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 7) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wh, o.dxl[jt], dc[jt], 0, 0, 0);
+            if (SPLIT && k == 8) dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.wl, o.dxh[jt], dc[jt], 0, 0, 0);
         }
     };
     auto mfma_ops = [&](const Ops& o) {
@@ -565,17 +586,17 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
         const int yy = y0 + 2 * jq + jt, xx = x0 + li;
         if (yy >= a.Hv || xx >= a.Wv) continue;
         const long o = ((long)z * a.Ho + yy) * a.Wo + xx;
-        h3_store<VEL>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
+        h3_store<VEL, SPLIT>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
     }
 }
 
-template <int MODE, bool VEL, bool HAS_DX, int XDEPTH>
+template <int MODE, bool VEL, bool HAS_DX, int XDEPTH, bool SPLIT>
 static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
-    typedef H3Geom<MODE> G;
+    typedef H3Geom<MODE, SPLIT> G;
     constexpr int WB = G::WP * (VEL ? 2 : 1), XB = G::XP * ((VEL && HAS_DX) ? 2 : 1);
     constexpr size_t smem = (size_t)(2 * WB + XDEPTH * XB) * 16 + TILE_VOX * sizeof(int);
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
-    auto kern = conv_h3_kernel<MODE, VEL, HAS_DX, XDEPTH>;
+    auto kern = conv_h3_kernel<MODE, VEL, HAS_DX, XDEPTH, SPLIT>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -585,12 +606,13 @@ static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
 }
 
-template <bool VEL, bool HAS_DX, int SCHED>
+template <bool VEL, bool HAS_DX, int SCHED, bool SPLIT>
 static void launch_h3p_t(ConvKArgs ka, int ctiles, hipStream_t s) {
-    constexpr int WB = 3 * 4 * 64 * (VEL ? 2 : 1), XB = HP_XPP * ((VEL && HAS_DX) ? 2 : 1);
+    constexpr int UN = SPLIT ? 4 : 2;
+    constexpr int WB = 3 * UN * 64 * (VEL ? 2 : 1), XB = ((UN * HP_PL + 63) / 64 * 64) * ((VEL && HAS_DX) ? 2 : 1);
     constexpr size_t smem = (size_t)(2 * WB + 2 * XB) * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
-    auto kern = conv_h3p_kernel<VEL, HAS_DX, SCHED>;
+    auto kern = conv_h3p_kernel<VEL, HAS_DX, SCHED, SPLIT>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -603,38 +625,43 @@ static void launch_h3p_t(ConvKArgs ka, int ctiles, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
 }
 
+template <int SCHED, bool SPLIT, bool VEL, bool HAS_DX>
+static void launch_h3p_v(const ConvKArgs& ka, int ct, hipStream_t s) { launch_h3p_t<VEL, HAS_DX, SCHED, SPLIT>(ka, ct, s); }
+template <int MODE, int XDEPTH, bool SPLIT, bool VEL, bool HAS_DX>
+static void launch_h3_v(const ConvKArgs& ka, int ct, hipStream_t s) { launch_h3_t<MODE, VEL, HAS_DX, XDEPTH, SPLIT>(ka, ct, s); }
+
 void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
     const int ct = pw.ctiles;
     static const int depth = (getenv("NBE_H3_DEPTH") && atoi(getenv("NBE_H3_DEPTH")) == 3) ? 3 : 2;
     static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
+    static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
+    const bool split = pw.prec == PREC_F16X3;
+#define NBE_VD(F, ...)                                                          \
+    if (vel) { if (has_dx) F<__VA_ARGS__, true, true>(ka, ct, s); else F<__VA_ARGS__, true, false>(ka, ct, s); } \
+    else F<__VA_ARGS__, false, false>(ka, ct, s);
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
-        static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
-        if (sched == 0) {
-            if (vel) { if (has_dx) launch_h3p_t<true, true, 0>(ka, ct, s); else launch_h3p_t<true, false, 0>(ka, ct, s); }
-            else launch_h3p_t<false, false, 0>(ka, ct, s);
-        } else {
-            if (vel) { if (has_dx) launch_h3p_t<true, true, 1>(ka, ct, s); else launch_h3p_t<true, false, 1>(ka, ct, s); }
-            else launch_h3p_t<false, false, 1>(ka, ct, s);
-        }
+        if (!split) { NBE_VD(launch_h3p_v, 0, false) }
+        else if (sched == 1) { NBE_VD(launch_h3p_v, 1, true) }
+        else { NBE_VD(launch_h3p_v, 0, true) }
         return;
     }
-#define NBE_DISPATCH_H3D(MODE, D)                                               \
-    if (vel) { if (has_dx) launch_h3_t<MODE, true, true, D>(ka, ct, s);         \
-               else launch_h3_t<MODE, true, false, D>(ka, ct, s); }             \
-    else launch_h3_t<MODE, false, false, D>(ka, ct, s);
-#define NBE_DISPATCH_H3(MODE) if (depth == 3) { NBE_DISPATCH_H3D(MODE, 3) } else { NBE_DISPATCH_H3D(MODE, 2) }
-    if (pw.mode == MODE_FLAT3) { NBE_DISPATCH_H3(MODE_FLAT3) }
-    else if (pw.mode == MODE_FLAT1) { NBE_DISPATCH_H3(MODE_FLAT1) }
-    else { NBE_DISPATCH_H3(MODE_DOWN) }
-#undef NBE_DISPATCH_H3
-#undef NBE_DISPATCH_H3D
+    if (pw.mode == MODE_FLAT3) {
+        if (!split) { NBE_VD(launch_h3_v, MODE_FLAT3, 2, false) }
+        else if (depth == 3) { NBE_VD(launch_h3_v, MODE_FLAT3, 3, true) }
+        else { NBE_VD(launch_h3_v, MODE_FLAT3, 2, true) }
+    } else if (pw.mode == MODE_FLAT1) {
+        if (!split) { NBE_VD(launch_h3_v, MODE_FLAT1, 2, false) } else { NBE_VD(launch_h3_v, MODE_FLAT1, 2, true) }
+    } else {
+        if (!split) { NBE_VD(launch_h3_v, MODE_DOWN, 2, false) } else { NBE_VD(launch_h3_v, MODE_DOWN, 2, true) }
+    }
+#undef NBE_VD
 }
 
 // packed layout: [set][ct][stage = chunk*nseg + seg][tap][u = 2*h + part][co 64][j 8];
 // channel = chunk*16 + 8*h + j; part 0 = hi, 1 = lo * 2^11
 __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ w, int cout, int cin, int kind,
                                                       int mode, int nchunk, long halves_per_set, int nsets,
-                                                      _Float16* __restrict__ dst) {
+                                                      int parts, _Float16* __restrict__ dst) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= halves_per_set * nsets) return;
     const int TAPS = mode_taps(mode), nseg = mode_nseg(mode);
@@ -642,14 +669,15 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
     long r = idx;
     const int j = (int)(r % 8); r /= 8;
     const int co = (int)(r % 64); r /= 64;
-    const int u = (int)(r % 4); r /= 4;
+    const int un = 2 * parts;
+    const int u = (int)(r % un); r /= un;
     const int tap = (int)(r % TAPS); r /= TAPS;
     const int stage = (int)(r % nstage); r /= nstage;
-    const long per_set_ct = halves_per_set / ((long)nstage * TAPS * 4 * 64 * 8);
+    const long per_set_ct = halves_per_set / ((long)nstage * TAPS * un * 64 * 8);
     const int ct = (int)(r % per_set_ct); r /= per_set_ct;
     const int set = (int)r;
     const int chunk = stage / nseg, seg = stage - chunk * nseg;
-    const int h = u >> 1, part = u & 1;
+    const int h = u / parts, part = u - h * parts;
     const int ci = chunk * 16 + 8 * h + j;
     const int oc = ct * 64 + co;
     int k, kz, ky, kx;
@@ -667,15 +695,22 @@ void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const Pac
     const long halves = pw.floats * 2;
     const long total = halves * pw.nsets;
     hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
-                       kind, pw.mode, pw.cin_pad / 16, halves, pw.nsets, (_Float16*)dst);
+                       kind, pw.mode, pw.cin_pad / 16, halves, pw.nsets, pw.prec == PREC_F16X3 ? 2 : 1, (_Float16*)dst);
 }
 
 // ------------------------------------------------------------------------------------------------
-// data movement in the 8 x f16 hi/lo plane format
+// data movement in the 8 x f16 plane formats: parts = 2 (f16x3: plane 2g = hi, 2g+1 = lo) or 1 (plain f16)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ half8 ld8(const float* base, long plane, long pstride, long v) {
+    return *(const half8*)(base + (plane * pstride + v) * 4);
+}
+__device__ __forceinline__ float join1(const half8& hi, const half8& lo, int e, int parts) {
+    return parts == 2 ? (float)hi[e] + (float)lo[e] * H3_INV : (float)hi[e];
+}
+
 __global__ __launch_bounds__(256) void gather_h8_kernel(const float* __restrict__ box, int C, int Db, int Hb, int Wb,
                                                         int a0, int a1, int a2, float* __restrict__ dst, long pstride,
-                                                        int G, int D, int H, int W, float scale) {
+                                                        int G, int D, int H, int W, float scale, int parts) {
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long V = (long)D * H * W;
     if (v >= V) return;
@@ -684,7 +719,7 @@ __global__ __launch_bounds__(256) void gather_h8_kernel(const float* __restrict_
     const int bz = ((a0 + z) % Db + Db) % Db, by = ((a1 + y) % Hb + Hb) % Hb, bx = ((a2 + x) % Wb + Wb) % Wb;
     const long bo = ((long)bz * Hb + by) * Wb + bx;
     const long bstride = (long)Db * Hb * Wb;
-    for (int g = 0; 2 * g < G; ++g) {
+    for (int g = 0; parts * g < G; ++g) {
         half8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -693,34 +728,35 @@ __global__ __launch_bounds__(256) void gather_h8_kernel(const float* __restrict_
             hi[e] = (_Float16)f;
             lo[e] = (_Float16)((f - (float)hi[e]) * H3_SCALE);
         }
-        *(half8*)(dst + ((long)(2 * g) * pstride + v) * 4) = hi;
-        *(half8*)(dst + ((long)(2 * g + 1) * pstride + v) * 4) = lo;
+        *(half8*)(dst + ((long)(parts * g) * pstride + v) * 4) = hi;
+        if (parts == 2) *(half8*)(dst + ((long)(2 * g + 1) * pstride + v) * 4) = lo;
     }
 }
 
 void launch_gather_h8(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                      float* dst, const Planes& geom, float scale, hipStream_t s) {
+                      float* dst, const Planes& geom, float scale, int parts, hipStream_t s) {
     const long V = geom.vox();
     hipLaunchKernelGGL(gather_h8_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, box, C, Db, Hb, Wb,
-                       a0, a1, a2, dst, geom.pstride, geom.G, geom.D, geom.H, geom.W, scale);
+                       a0, a1, a2, dst, geom.pstride, geom.G, geom.D, geom.H, geom.W, scale, parts);
 }
 
 __global__ __launch_bounds__(256) void from_planes_h8_kernel(const float* __restrict__ src, long pstride, long V, int C,
-                                                             float* __restrict__ dst) {
+                                                             float* __restrict__ dst, int parts) {
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     for (int g = 0; 8 * g < C; ++g) {
-        const half8 hi = *(const half8*)(src + ((long)(2 * g) * pstride + v) * 4);
-        const half8 lo = *(const half8*)(src + ((long)(2 * g + 1) * pstride + v) * 4);
+        const half8 hi = ld8(src, parts * g, pstride, v);
+        const half8 lo = parts == 2 ? ld8(src, 2 * g + 1, pstride, v) : hi;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            if (8 * g + e < C) dst[(long)(8 * g + e) * V + v] = (float)hi[e] + (float)lo[e] * H3_INV;
+            if (8 * g + e < C) dst[(long)(8 * g + e) * V + v] = join1(hi, lo, e, parts);
     }
 }
 
-void launch_from_planes_h8(const float* src, const Planes& geom, int C, float* dst, hipStream_t s) {
+void launch_from_planes_h8(const float* src, const Planes& geom, int C, float* dst, int parts, hipStream_t s) {
     const long V = geom.vox();
-    hipLaunchKernelGGL(from_planes_h8_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, src, geom.pstride, V, C, dst);
+    hipLaunchKernelGGL(from_planes_h8_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, src, geom.pstride, V, C,
+                       dst, parts);
 }
 
 template <typename OT>
@@ -729,7 +765,7 @@ __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ 
                                                       const float* __restrict__ xin, long xpstride, int XH, int XW,
                                                       int c0, int C, float k_dy, float k_x0, OT* __restrict__ disp,
                                                       OT* __restrict__ velo, int Db, int Hb, int Wb, int a0, int a1,
-                                                      int a2) {
+                                                      int a2, int parts) {
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long V = (long)D * H * W;
     if (v >= V) return;
@@ -739,24 +775,18 @@ __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ 
     const long bo = ((long)(a0 + z) * Hb + (a1 + yy)) * Wb + (a2 + x);
     const long bstride = (long)Db * Hb * Wb;
     for (int g = 0; 8 * g < C; ++g) {
-        const half8 yh = *(const half8*)(y + ((long)(2 * g) * ypstride + v) * 4);
-        const half8 yl = *(const half8*)(y + ((long)(2 * g + 1) * ypstride + v) * 4);
-        const half8 xh = *(const half8*)(xin + ((long)(2 * g) * xpstride + xv) * 4);
-        const half8 xl = *(const half8*)(xin + ((long)(2 * g + 1) * xpstride + xv) * 4);
-        half8 dh, dl;
-        if (dy) { dh = *(const half8*)(dy + ((long)(2 * g) * ypstride + v) * 4);
-                  dl = *(const half8*)(dy + ((long)(2 * g + 1) * ypstride + v) * 4); }
+        const half8 yh = ld8(y, parts * g, ypstride, v), xh = ld8(xin, parts * g, xpstride, xv);
+        const half8 yl = parts == 2 ? ld8(y, 2 * g + 1, ypstride, v) : yh;
+        const half8 xl = parts == 2 ? ld8(xin, 2 * g + 1, xpstride, xv) : xh;
+        half8 dh = yh, dl = yh;
+        if (dy) { dh = ld8(dy, parts * g, ypstride, v); dl = parts == 2 ? ld8(dy, 2 * g + 1, ypstride, v) : dh; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = 8 * g + e;
             if (c < C) {
-                const float yv = (float)yh[e] + (float)yl[e] * H3_INV;
-                const float x0 = (float)xh[e] + (float)xl[e] * H3_INV;
+                const float yv = join1(yh, yl, e, parts), x0 = join1(xh, xl, e, parts);
                 disp[c * bstride + bo] = (OT)((yv + x0) * 6.0f);
-                if (dy) {
-                    const float dv = (float)dh[e] + (float)dl[e] * H3_INV;
-                    velo[c * bstride + bo] = (OT)(dv * k_dy + x0 * k_x0);
-                }
+                if (dy) velo[c * bstride + bo] = (OT)(join1(dh, dl, e, parts) * k_dy + x0 * k_x0);
             }
         }
     }
@@ -764,18 +794,18 @@ __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ 
 
 void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                     void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                    hipStream_t s) {
+                    int parts, hipStream_t s) {
     const long V = y.vox();
     const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
     dim3 grid((unsigned)((V + 255) / 256)), block(256);
     if (out_dtype == 0)
         hipLaunchKernelGGL(head_h8_kernel<float>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D, y.H,
                            y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (float*)disp, (float*)velo,
-                           Db, Hb, Wb, a0, a1, a2);
+                           Db, Hb, Wb, a0, a1, a2, parts);
     else
         hipLaunchKernelGGL(head_h8_kernel<_Float16>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D,
                            y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (_Float16*)disp,
-                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2);
+                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, parts);
 }
 
 }  // namespace nbe

@@ -46,12 +46,13 @@ def params_fingerprint(params):
 
 
 class Engine:
-    PRECISIONS = {"f32": 0, "f16x3": 1}
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2}
 
     def __init__(self, device=0, in_chan=3, out_chan=3, mid_chan=64, eps=1e-8, compute_vel=True, precision=None):
         """precision: "f16x3" (float32-equivalent split-f16 MFMA: three f16 MFMAs per product, float32
         accumulation; whole-network error vs float64 at or below the strict path's) or "f32" (strict float32
-        MFMA).  Default: the environment variable NBE_PRECISION, else "f16x3"."""
+        MFMA) or "f16" (plain float16 operands, float32 accumulation: the reference's dtype=float16 arithmetic).
+        Default: the environment variable NBE_PRECISION, else "f16x3"."""
         import os
         self._l = _lib.lib()
         if precision is None:
@@ -133,7 +134,13 @@ class Engine:
         check(self._l.nbe_set_cosmology(self._h, float(Om), float(Dz)))
 
     def set_stream(self, stream_ptr):
+        """Run on the hipStream_t `stream_ptr` (0 / None = the device's null stream)."""
         check(self._l.nbe_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+        self._stream_ptr = int(stream_ptr or 0)
+
+    def use_own_stream(self):
+        check(self._l.nbe_use_own_stream(self._h))
+        self._stream_ptr = None
 
     def set_max_tile(self, max_tile):
         """0 = run exactly the caller's sub-box grid; N = merge sub-boxes into tiles of edge <= N."""
@@ -157,10 +164,9 @@ class Engine:
     def _follow_torch_stream(self):
         """CUDA tensors in/out: enqueue on torch's current stream so that torch ops before and after
         this call are ordered with the kernels (device pointers make the C calls asynchronous)."""
-        sp = torch.cuda.current_stream().cuda_stream
+        sp = int(torch.cuda.current_stream().cuda_stream)      # 0 = torch's default = the null stream
         if getattr(self, '_stream_ptr', None) != sp:
             self.set_stream(sp)
-            self._stream_ptr = sp
 
     # ---- compute ------------------------------------------------------------------------------
     def forward(self, x, Dz, vel_fac=0.0):

@@ -8,8 +8,10 @@
 They hold no arithmetic: `apply` hands the parameter tree and the input to the HIP
 engine through the C ABI (engine.py -> libnbe.so).  `x` is (B, C, D, H, W), a NumPy
 array (host, copied over PCIe) or a CUDA torch tensor (stays resident); outputs come
-back as the same kind, in x's dtype.  Compute is float32; float16/bfloat16 inputs are
-accepted and rounded on the way in and out (the reference would convolve in that dtype).
+back as the same kind, in x's dtype.  The arithmetic follows x's dtype as in the reference
+(style_layers_vel.py:103-105): float32 input -> the float32-equivalent engine (NBE_PRECISION,
+default "f16x3"), float16 input -> the float16 engine ("f16": f16 operands, float32
+accumulation).  bfloat16 input is rounded on the way in and out of the float32 engine.
 """
 
 from dataclasses import dataclass
@@ -21,12 +23,24 @@ from . import engine as _engine
 _ENGINES = {}
 
 
-def get_engine(model, device=None):
-    """One engine (context + weights + workspace) per (device, architecture, variant)."""
+def precision_for(dtype):
+    """Engine arithmetic for a model dtype: float16 -> "f16", everything else -> NBE_PRECISION / "f16x3"."""
+    import os
+    is_f16 = False
+    if dtype is not None:
+        if _engine.torch is not None and isinstance(dtype, _engine.torch.dtype):
+            is_f16 = dtype == _engine.torch.float16
+        else:
+            is_f16 = np.dtype(dtype) == np.float16
+    return "f16" if is_f16 else os.environ.get("NBE_PRECISION", "f16x3")
+
+
+def get_engine(model, device=None, precision=None):
+    """One engine (context + weights + workspace) per (device, architecture, variant, arithmetic)."""
     if device is None:
         device = 0
-    import os
-    precision = os.environ.get("NBE_PRECISION", "f16x3")
+    if precision is None:
+        precision = precision_for(None)
     key = (int(device), model.in_chan, model.out_chan, model.mid_chan, float(model.eps), model._compute_vel, precision)
     if getattr(model, 'style_size', 2) != 2:
         raise ValueError("style_size must be 2: the style vector is ((Om-0.3)*5, Dz-1)")
@@ -121,7 +135,7 @@ class _Core:
             is_t = False
         if is_t and device is None:
             device = x.device.index or 0
-        eng = get_engine(self, device)
+        eng = get_engine(self, device, precision_for(x.dtype))
         eng.ensure_params(params, self._premodulate)
         B = x.shape[0]
         bc = lambda v: None if v is None else np.broadcast_to(np.atleast_1d(np.asarray(v, dtype=np.float32)).ravel(), (B,))
@@ -132,8 +146,7 @@ class _Core:
             if not self._premodulate:
                 eng.set_cosmology(Om_[i], Dz_[i])
             xi = x[i]
-            if not is_t:
-                xi = np.asarray(xi).astype(np.float32, copy=False)
+            xi = xi.float() if is_t else np.asarray(xi).astype(np.float32, copy=False)
             r = eng.forward(xi, Dz_[i], 0.0 if vf_ is None else vf_[i])
             if self._compute_vel:
                 ds.append(r[0]); vs.append(r[1])

@@ -26,7 +26,7 @@ class SubboxConfig:
     Attributes:
         size: Full box size (D, H, W)
         ndiv: Number of divisions along each dimension
-        dtype: Precision of the model input/output (float32; float16 is rounded through)
+        dtype: Precision of the model (float32 -> float32-equivalent engine; float16 -> float16 engine)
         output_dtype: Precision for output arrays (np.float16 or np.float32)
         in_chan: Number of input channels (default: 3 for displacement)
         padding: Padding on each side for each dimension
@@ -114,7 +114,7 @@ class SubboxProcessor:
         if is_t and not input_box.is_cuda:
             input_box, is_t = input_box.numpy(), False
         device = (input_box.device.index or 0) if is_t else None
-        eng = _models.get_engine(self.model, device)
+        eng = _models.get_engine(self.model, device, _models.precision_for(cfg.dtype))
         eng.ensure_params(self.params, self.premodulate)
 
         # cosmology once per box (subbox.py:173-178), float32 like the reference

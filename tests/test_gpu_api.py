@@ -91,6 +91,32 @@ def test_process_box_matches_golden_and_reference_semantics(precision):
     np.testing.assert_allclose(d16.astype(np.float32), dis, rtol=2e-3, atol=2e-3)
 
 
+def test_process_box_float16_model():
+    """SubboxConfig(dtype=float16) (the reference's fastest rows, README.md:245-250; tests/test_subbox.py:598-625)
+    selects the float16 engine; tile merging does not change the field beyond float16 rounding."""
+    seed_p, seed_x, mid, s0, s1, s2, n0, n1, n2 = (int(v) for v in GOLD["pbox_meta"])
+    p = _synthetic(seed_p, mid)
+    box = np.random.default_rng(seed_x).standard_normal((3, s0, s1, s2)).astype(np.float32)
+    cfg = J.SubboxConfig(size=(s0, s1, s2), ndiv=(n0, n1, n2), dtype=np.float16)
+    emu = J.create_emulator(load_params=False, processor_config=cfg, mid_chan=mid)
+    emu.processor.params = p
+    dis, vel = emu.process_box(box, Z, OM, show_progress=False)
+    assert dis.dtype == np.float32 and np.all(np.isfinite(dis)) and np.all(np.isfinite(vel))
+    e = rel_l2(dis, GOLD["pbox_disp"]), rel_l2(vel, GOLD["pbox_vel"])
+    print("process_box f16: disp rel_l2 %.3e vel rel_l2 %.3e" % e)
+    assert e[0] <= 2e-3 and e[1] <= 4e-2
+    from jax_nbody_emulator_with_dj_amd import models
+    eng = models.get_engine(emu.model, None, "f16")
+    assert eng.precision == "f16"
+    eng.set_max_tile(0)                                         # the caller's grid, no merging
+    try:
+        dis0, vel0 = emu.process_box(box, Z, OM, show_progress=False)
+    finally:
+        eng.set_max_tile(256)
+    # same per-voxel arithmetic; float32 sums may differ in the last bit and flip a float16 rounding
+    assert rel_l2(dis, dis0) <= 1e-3 and rel_l2(vel, vel0) <= 1e-2
+
+
 def test_trailing_voxels_stay_zero():
     """size % ndiv != 0: crop_size floors and the remainder is never written (subbox.py:49, :168-170)."""
     p = _synthetic(3, 8)

@@ -71,6 +71,41 @@ def test_premod_vel_small(engine_factory, small, prec):
     _check(d, v, d_o, v_o, "premod-vel mid8")
 
 
+def test_float16_mode(engine_factory, small):
+    """The float16 engine ("f16": float16 operands and stored activations, float32 accumulation -- the
+    arithmetic of the reference's dtype=float16 configuration) against the float64 oracle.  Every one of the
+    ~21 sequential layers rounds its operands to 11 significant bits, and the velocity is a tangent through
+    all of them; a NumPy emulation of exactly that rounding gives rel-L2 4e-4 (disp) / 1.4e-2 (vel) at
+    mid_chan=64.  Tolerance: rel-L2 <= 2e-3 (disp), <= 4e-2 (vel)."""
+    import os
+    from oracle import params as P
+    p, x, d_o, v_o = small
+    e = engine_factory(mid_chan=8, compute_vel=True, precision="f16")
+    e.load_params(p, premodulated=False)
+    e.set_cosmology(OM, DZ)
+    d, v = e.forward(x, DZ, VF)
+    assert np.all(np.isfinite(d)) and np.all(np.isfinite(v))
+    print("f16 mid8: disp rel_l2 %.3e vel rel_l2 %.3e" % (rel_l2(d, d_o), rel_l2(v, v_o)))
+    assert rel_l2(d, d_o) <= 2e-3 and rel_l2(v, v_o) <= 4e-2
+    d2, v2 = e.forward(x, DZ, VF)
+    assert np.array_equal(d, d2) and np.array_equal(v, v2)
+    e0 = engine_factory(mid_chan=8, compute_vel=False, precision="f16")
+    e0.load_params(p, premodulated=False)
+    e0.set_cosmology(OM, DZ)
+    assert np.array_equal(e0.forward(x, DZ), d)                 # the primal does not depend on the tangent path
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+    seed_p, seed_x, mid, d0, d1, d2_ = (int(t) for t in gold["net64_meta"])
+    p = P.synthetic_params(seed=seed_p, mid_chan=mid)
+    x = np.random.default_rng(seed_x).standard_normal((1, 3, d0, d1, d2_)).astype(np.float32)[0]
+    e = engine_factory(mid_chan=mid, compute_vel=True, precision="f16")
+    e.load_params(p, premodulated=False)
+    e.set_cosmology(OM, DZ)
+    d, v = e.forward(x, DZ, VF)
+    print("f16 mid64: disp rel_l2 %.3e vel rel_l2 %.3e" % (rel_l2(d, gold["net64_disp"]), rel_l2(v, gold["net64_vel"])))
+    assert rel_l2(d, gold["net64_disp"]) <= 2e-3 and rel_l2(v, gold["net64_vel"]) <= 4e-2
+
+
 def test_full_width_c1_slice(engine_factory):
     """mid_chan=64 (production width) on the smallest legal input, against the committed golden
     fixture (float64 oracle output, tests/golden/make_golden.py), both arithmetic modes."""
