@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbe.so")
+LIB_PATH = os.environ.get("NBE_LIB") or os.path.join(_HERE, "libnbe.so")   # NBE_LIB: timing-probe builds only
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ("nbe_kernels.hip", "nbe_kernels_h3.hip", "nbe_engine.cpp")
 
