@@ -115,6 +115,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    phases = {}
+
     def measure(precision, warmup, steps):
         """W untimed + K timed passes of the whole box with one arithmetic mode."""
         nonlocal sb
@@ -132,6 +134,7 @@ def main():
         for _ in range(warmup):
             step()
         fence()
+        eng.debug_phase_cycles()                  # timing-probe builds: reset the in-kernel phase counters
         eng.profile_reset()
         eng.profile_enable(True)
         t0 = time.perf_counter()
@@ -141,6 +144,13 @@ def main():
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
         prof = eng.profile_read()
+        ph = eng.debug_phase_cycles()
+        if ph[8] > 0:                             # NBE_BUILD_DBG=1 only: where the dominant kernel's wave cycles go
+            tot = sum(ph[:8])
+            phases.update({k: round(v / tot, 4) for k, v in zip(
+                ("prologue", "stage_a_compute", "stage_a_own_dma", "stage_a_barrier", "stage_b_compute", "stage_b_own_dma",
+                 "stage_b_barrier", "epilogue"), ph)})
+            phases["cycles_per_wave"] = round(tot / ph[8])
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,6 +203,8 @@ def main():
             out["kernels"] = [{"kernel": e["kernel"], "ms": round(e["ms"], 3), "launches": e["launches"],
                                "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
                               for e in sorted(prof, key=lambda e: -e["ms"])]
+        if phases:
+            out["phase_cycles_debug_build"] = phases
         if strict is not None:
             sdt, sprof, sok, _ = strict
             out["strict_f32"] = {"value": vox / sdt, "unit": "voxels/s", "ms_per_step": 1e3 * sdt, "steps": 1,

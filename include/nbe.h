@@ -140,6 +140,10 @@ int nbe_profile_count(nbe_ctx* ctx);
 int nbe_profile_entry(nbe_ctx* ctx, int i, char* name, int name_cap, double* ms, int64_t* launches, double* flops);
 /* bytes of device workspace currently held */
 int64_t nbe_workspace_bytes(nbe_ctx* ctx);
+/* timing-probe builds (-DNBE_DBG=1) only: s_memtime cycle totals per phase of the f16x3 3x3x3 kernel, summed over
+ * waves since the last call: [0] prologue; [1]/[4] compute of the two stages of a (chunk, dz) group, [2]/[5] wait for
+ * the wave's own DMA, [3]/[6] wait at the barrier; [7] epilogue; [8] number of waves.  Production builds return zeros. */
+int nbe_debug_phase_cycles(nbe_ctx* ctx, double* out16);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,7 @@ SIGNATURES = {
     "nbe_profile_entry": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "nbe_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "nbe_debug_phase_cycles": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -904,4 +904,10 @@ int nbe_profile_entry(nbe_ctx* c, int i, char* name, int cap, double* ms, int64_
 }
 int64_t nbe_workspace_bytes(nbe_ctx* c) { return c ? c->ws_bytes : 0; }
 
+int nbe_debug_phase_cycles(nbe_ctx* c, double* out16) {
+    if (!c || !out16) return fail("null argument");
+    h3q_read_stamps(out16, c->stream);
+    return 0;
+}
+
 }  // extern "C"

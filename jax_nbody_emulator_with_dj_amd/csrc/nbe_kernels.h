@@ -95,4 +95,7 @@ void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, fl
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
                  int prec, hipStream_t s);
 
+// NBE_DBG builds: per-phase cycle totals of the f16x3 3x3x3 kernel since the last call (zeros otherwise)
+void h3q_read_stamps(double* out16, hipStream_t s);
+
 }  // namespace nbe

@@ -16,6 +16,7 @@
 
 #include "nbe_kernels_internal.h"
 #include <cstdlib>
+#include <algorithm>
 
 #ifndef NBE_DBG
 #define NBE_DBG 0          // 1: compile the timing-experiment switches (python: NBE_BUILD_DBG=1)
@@ -42,41 +43,60 @@ __device__ __forceinline__ f32x4 join4(const half4 hi, const half4 lo) {
     return v;
 }
 
-// Epilogue of one 32x32 accumulator tile for output voxel `o` (this lane's column): join main + correction,
-// bias, residual, LeakyReLU (+ tangent) in float32, then split to hi/lo and store 4 channels (8 B) per part.
-// it = cout half of the wave, lh = lane half; register 4k+e of the tile is cout 32*it + 8k + 4*lh + e.
+// Epilogue of the two 32x32 accumulator tiles of a wave (column tiles jt = 0, 1; this lane's output voxels o[jt]):
+// join main + correction, bias, residual, LeakyReLU (+ tangent) in float32, then split to hi/lo and store 4 channels
+// (8 B) per part.  it = cout half of the wave, lh = lane half; register 4k+e of a tile is cout 32*it + 8k + 4*lh + e.
+// Every global load (bias, residuals of all 8 (jt, k) pieces) is issued before the first use: written piece by
+// piece, each piece's loads wait for the previous piece's stores (vmcnt counts both) and the epilogue serialises on
+// memory latency.  Lanes without a valid voxel (ok[jt] false) must pass a valid dummy o[jt]; they skip the stores.
 template <bool VEL, bool SPLIT>
-__device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int lh, long o, const f32x16& ym,
-                                         const f32x16& yc, const f32x16& dm, const f32x16& dc) {
+__device__ __forceinline__ void h3_store2(const ConvKArgs& a, int ct, int it, int lh, const long (&o)[2],
+                                          const bool (&ok)[2], const f32x16 (&ym)[2], const f32x16 (&yc)[2],
+                                          const f32x16 (&dm)[2], const f32x16 (&dc)[2]) {
     constexpr int PARTS = SPLIT ? 2 : 1;
     const bool act = a.flags & F_ACT, res = a.flags & F_RES;
-    char* const yb = (char*)a.y;
-    char* const dyb = (char*)a.dy;
+    int unit[4];
+    bool uok[4];
+    f32x4 bv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int unit = ct * 8 + 4 * it + k;                    // 8-channel group of the output
-        if (unit >= a.cout_groups) continue;
-        const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * lh);
+        unit[k] = ct * 8 + 4 * it + k;                           // 8-channel group of the output
+        uok[k] = unit[k] < a.cout_groups;
+        if (!uok[k]) unit[k] = a.cout_groups - 1;
+        bv[k] = *(const f32x4*)(a.bias + unit[k] * 8 + 4 * lh);
+    }
+    half4 rh[8], rl[8], dh[8], dl[8];
+    if (res) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long rb = ((long)(PARTS * unit[p & 3]) * a.res_pstride + o[p >> 2]) * 16 + 8 * lh;
+            const long rlo = rb + a.res_pstride * 16;
+            rh[p] = *(const half4*)((const char*)a.r + rb);
+            if (SPLIT) rl[p] = *(const half4*)((const char*)a.r + rlo);
+            if (VEL) {
+                dh[p] = *(const half4*)((const char*)a.dr + rb);
+                if (SPLIT) dl[p] = *(const half4*)((const char*)a.dr + rlo);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int jt = p >> 2, k = p & 3;
         f32x4 v, dv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = ym[4 * k + e] + (SPLIT ? yc[4 * k + e] * H3_INV : 0.f) + bv[e];
-            dv[e] = dm[4 * k + e] + (SPLIT ? dc[4 * k + e] * H3_INV : 0.f);
+            v[e] = ym[jt][4 * k + e] + (SPLIT ? yc[jt][4 * k + e] * H3_INV : 0.f) + bv[k][e];
+            dv[e] = dm[jt][4 * k + e] + (SPLIT ? dc[jt][4 * k + e] * H3_INV : 0.f);
         }
         if (res) {
-            const long rb = ((long)(PARTS * unit) * a.res_pstride + o) * 16 + 8 * lh;
-            const long rl = rb + a.res_pstride * 16;
             if (SPLIT) {
-                v += join4(*(const half4*)((const char*)a.r + rb), *(const half4*)((const char*)a.r + rl));
-                if (VEL) dv += join4(*(const half4*)((const char*)a.dr + rb), *(const half4*)((const char*)a.dr + rl));
+                v += join4(rh[p], rl[p]);
+                if (VEL) dv += join4(dh[p], dl[p]);
             } else {
-                const half4 rh = *(const half4*)((const char*)a.r + rb);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rh[e];
-                if (VEL) {
-                    const half4 dh = *(const half4*)((const char*)a.dr + rb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dv[e] += (float)dh[e];
+                for (int e = 0; e < 4; ++e) {
+                    v[e] += (float)rh[p][e];
+                    if (VEL) dv[e] += (float)dh[p][e];
                 }
             }
         }
@@ -87,16 +107,18 @@ __device__ __forceinline__ void h3_store(const ConvKArgs& a, int ct, int it, int
                 v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
             }
         }
-        const long ob = ((long)(a.out_g0 + PARTS * unit) * a.out_pstride + o) * 16 + 8 * lh;
-        const long ol = ob + a.out_pstride * 16;
-        half4 hi, lo;
-        split4(v, hi, lo);
-        *(half4*)(yb + ob) = hi;
-        if (SPLIT) *(half4*)(yb + ol) = lo;
-        if (VEL) {
-            split4(dv, hi, lo);
-            *(half4*)(dyb + ob) = hi;
-            if (SPLIT) *(half4*)(dyb + ol) = lo;
+        if (uok[k] && ok[jt]) {
+            const long ob = ((long)(a.out_g0 + PARTS * unit[k]) * a.out_pstride + o[jt]) * 16 + 8 * lh;
+            const long ol = ob + a.out_pstride * 16;
+            half4 hi, lo;
+            split4(v, hi, lo);
+            *(half4*)((char*)a.y + ob) = hi;
+            if (SPLIT) *(half4*)((char*)a.y + ol) = lo;
+            if (VEL) {
+                split4(dv, hi, lo);
+                *(half4*)((char*)a.dy + ob) = hi;
+                if (SPLIT) *(half4*)((char*)a.dy + ol) = lo;
+            }
         }
     }
 }
@@ -326,22 +348,23 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    long o[2];
+    bool ok[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         const long q = q0 + jq * 64 + 32 * jt + li;
-        bool valid = q < a.Q;
-        long o;
+        ok[jt] = q < a.Q;
         if (MODE == MODE_DOWN) {
-            o = q;
+            o[jt] = q;
         } else {
             const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
             const int yy = rem / a.W, xx = rem - yy * a.W;
-            valid = valid && xx < a.Wv && yy < a.Hv && z < a.Dv;
-            o = ((long)(z * a.osz + a.oz) * a.Ho + (yy * a.osz + a.oy)) * a.Wo + (xx * a.osz + a.ox);
+            ok[jt] = ok[jt] && xx < a.Wv && yy < a.Hv && z < a.Dv;
+            o[jt] = ((long)(z * a.osz + a.oz) * a.Ho + (yy * a.osz + a.oy)) * a.Wo + (xx * a.osz + a.ox);
         }
-        if (!valid) continue;
-        h3_store<VEL, SPLIT>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
+        if (!ok[jt]) o[jt] = 0;
     }
+    h3_store2<VEL, SPLIT>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,13 +632,15 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
     }
 
     // ---- epilogue: rows y0 + 2*jq + jt, column x0 + li of output plane z
+    long o[2];
+    bool ok[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         const int yy = y0 + 2 * jq + jt, xx = x0 + li;
-        if (yy >= a.Hv || xx >= a.Wv) continue;
-        const long o = ((long)z * a.Ho + yy) * a.Wo + xx;
-        h3_store<VEL, SPLIT>(a, ct, it, lh, o, ym[jt], yc[jt], dm[jt], dc[jt]);
+        ok[jt] = yy < a.Hv && xx < a.Wv;
+        o[jt] = ok[jt] ? ((long)z * a.Ho + yy) * a.Wo + xx : (long)z * a.Ho * a.Wo;
     }
+    h3_store2<VEL, SPLIT>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -655,42 +680,32 @@ __device__ __forceinline__ void dma16s(const char* ubase, unsigned voff, f32x4* 
     __builtin_amdgcn_global_load_lds((const NBE_GLB_AS void*)(ubase + voff), (NBE_LDS_AS void*)dst_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ void h3_store16(const ConvKArgs& a, int unit, int half, long o, const f32x4& ym,
-                                           const f32x4& yc, const f32x4& dm, const f32x4& dc) {
-    if (unit >= a.cout_groups) return;
-    const bool act = a.flags & F_ACT, res = a.flags & F_RES;
-    const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * half);
-    f32x4 v, dv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        v[e] = ym[e] + yc[e] * H3_INV + bv[e];
-        dv[e] = dm[e] + dc[e] * H3_INV;
-    }
-    if (res) {
-        const long rb = ((long)(2 * unit) * a.res_pstride + o) * 16 + 8 * half;
-        const long rl = rb + a.res_pstride * 16;
-        v += join4(*(const half4*)((const char*)a.r + rb), *(const half4*)((const char*)a.r + rl));
-        dv += join4(*(const half4*)((const char*)a.dr + rb), *(const half4*)((const char*)a.dr + rl));
-    }
-    if (act) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
-            v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
-        }
-    }
-    const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + o) * 16 + 8 * half;
-    const long ol = ob + a.out_pstride * 16;
-    half4 hi, lo;
-    split4(v, hi, lo);
-    *(half4*)((char*)a.y + ob) = hi;
-    *(half4*)((char*)a.y + ol) = lo;
-    split4(dv, hi, lo);
-    *(half4*)((char*)a.dy + ob) = hi;
-    *(half4*)((char*)a.dy + ol) = lo;
+// NBE_DBG builds: per-wave cycle totals (s_memtime) of the phases of conv_h3q_kernel, stamped only where the wave
+// drains its counters anyway (around the barriers): 0 prologue; 1 / 4 compute of the first / second stage of a
+// group, 2 / 5 the wait for its own DMA (vmcnt) and 3 / 6 the wait at the barrier that ends the stage; 7 epilogue;
+// 8 waves.  Written to memory nothing else reads.
+__device__ unsigned long long h3q_stamps[16];
+
+void h3q_read_stamps(double* out, hipStream_t s) {
+    unsigned long long h[16] = {0};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(h3q_stamps), sizeof h, 0, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 16; ++i) out[i] = (double)h[i];
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(h3q_stamps), z, sizeof z, 0, hipMemcpyHostToDevice);
 }
 
 __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
+#if NBE_DBG
+    unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NBE_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[i] += t_ - tk0; tk0 = t_; }
+// the barrier that ends a stage, its two waits stamped separately (i: compute, i+1: own DMA, i+2: other waves)
+#define NBE_STAGE_END(i, keep) { NBE_STAMP(i) wait_keep(keep); NBE_STAMP(i + 1) \
+                                 asm volatile("s_barrier" ::: "memory"); NBE_STAMP(i + 2) }
+#else
+#define NBE_STAMP(i)
+#define NBE_STAGE_END(i, keep) { wait_keep(keep); asm volatile("s_barrier" ::: "memory"); }
+#endif
     f32x4* lds = lds_h3;
     const half8* L8 = (const half8*)lds_h3;
     const int tid = threadIdx.x;
@@ -699,6 +714,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
     const int it = wave & 1, jq = wave >> 1;
 
+    // tile -> (ty, tx, z), z fastest: the 32 workgroups an XCD runs at the same time work on neighbouring planes of one
+    // patch column and share two of their three input planes through that XCD's L2.  (Persistent workgroups were
+    // measured on one device: a run of planes per workgroup loses that sharing, -12 %; a run of patches along x keeps
+    // it but gains < 1 % over the same code with runs of one, and carrying the epilogue inside a loop costs 6 %.)
     const int tile = xcd_tile(blockIdx.x, a.ntiles);
     const int ct = blockIdx.y;
     const int z = tile % a.Dv, tyx = tile / a.Dv;
@@ -770,15 +789,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     };
     // one product on the wave tile: 8 MFMAs.  kind 1 / 2 (first / second stage of a group) issues the DMA slots
     // `slot` and `slot + 1` after the 4th and the 8th MFMA: slots 0-4 weights of the next stage, 5-7 the x / dx
-    // patch of the next group.
-    auto MM8 = [&](f32x4 (&acc)[8], const half8 (&A)[2], const half8 (&B)[4], int kind, int slot, int g, long xo,
-                   int nb, bool px) {
+    // patch of the next group.  (Issuing both patches in the first stage and leaving them in flight across its
+    // barrier with a counted vmcnt was measured on one device: dx only -0.6 %, x and dx -2.5 %.)
+    auto MM8 = [&](f32x4 (&acc)[8], const half8 (&A)[2], const half8 (&B)[4], int kind, int slot, int g, int gn,
+                   long xo, int nb, bool px) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             mm(acc[t], A[t >> 2], B[t & 3]);
             if (kind != 0 && (t & 3) == 3) {
                 const int k = slot + (t >> 2);
-                if (k < 5) { if (kind == 1) dma_w(g, 1, k); else if (px) dma_w(g + 1, 0, k); }
+                if (k < 5) { if (kind == 1) dma_w(g, 1, k); else if (px) dma_w(gn + 1, 0, k); }
                 else if (k < 8 && px) dma_x(kind == 1 ? 0 : 1, k - 5, xo, nb);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -789,23 +809,31 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     // A tap pair: nine products in an order that keeps at most 80 operand registers alive, every operand requested
     // two or three products (256-384 cycles) before its first use.  On entry dwh, xl and xh of the pair are loaded
     // (or in flight); pre6 / pre7 request those of whatever follows.
-    auto pair = [&](int kind, int g, long xo, int nb, bool px, int wa /* buffer + tap offset */, int wset,
+    auto pair = [&](int kind, int g, int gn, long xo, int nb, bool px, int wa /* buffer + tap offset */, int wset,
                     int xp /* patch + shift + lane base */, auto&& pre6, auto&& pre7) {
         LA(wh, wa + aP); LA(dwl, wa + wset + 64 + aP);
-        NBE_SB; MM8(dc, dwh, xl, kind, 0, g, xo, nb, px); NBE_SB;
+        NBE_SB; MM8(dc, dwh, xl, kind, 0, g, gn, xo, nb, px); NBE_SB;
         LA(wl, wa + 64 + aP);
-        NBE_SB; MM8(dm, dwh, xh, kind, 2, g, xo, nb, px); NBE_SB;
-        MM8(yc, wh, xl, kind, 4, g, xo, nb, px); NBE_SB;
+        NBE_SB; MM8(dm, dwh, xh, kind, 2, g, gn, xo, nb, px); NBE_SB;
+        MM8(yc, wh, xl, kind, 4, g, gn, xo, nb, px); NBE_SB;
         LB(dxh, xp + HQ_XT);
-        NBE_SB; MM8(dc, dwl, xh, kind, 6, g, xo, nb, px); NBE_SB;
-        MM8(yc, wl, xh, 0, 0, g, xo, nb, px); NBE_SB;
+        NBE_SB; MM8(dc, dwl, xh, kind, 6, g, gn, xo, nb, px); NBE_SB;
+        MM8(yc, wl, xh, 0, 0, g, gn, xo, nb, px); NBE_SB;
         LB(dxl, xp + HQ_XT + HP_PL);
-        NBE_SB; MM8(ym, wh, xh, 0, 0, g, xo, nb, px); NBE_SB;
+        NBE_SB; MM8(ym, wh, xh, 0, 0, g, gn, xo, nb, px); NBE_SB;
         pre6();
-        NBE_SB; MM8(dc, wl, dxh, 0, 0, g, xo, nb, px); NBE_SB;
+        NBE_SB; MM8(dc, wl, dxh, 0, 0, g, gn, xo, nb, px); NBE_SB;
         pre7();
-        NBE_SB; MM8(dm, wh, dxh, 0, 0, g, xo, nb, px); NBE_SB;
-        MM8(dc, wh, dxl, 0, 0, g, xo, nb, px); NBE_SB;
+        NBE_SB; MM8(dm, wh, dxh, 0, 0, g, gn, xo, nb, px); NBE_SB;
+        MM8(dc, wh, dxl, 0, 0, g, gn, xo, nb, px); NBE_SB;
+    };
+
+    // wait until at most `keep` of this wave's DMA instructions are outstanding (vmcnt counts in issue order), and for
+    // its LDS reads
+    auto wait_keep = [&](int keep) {
+        if (keep >= 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (keep == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
 
     // ---- prologue: both patches of group 0 and the weights of its first stage
@@ -816,6 +844,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) dma_w(0, 0, t);
         __syncthreads();
+        NBE_STAMP(0)
         LB(xl, HQ_XBASE + bP1 + HP_PL);
         LB(xh, HQ_XBASE + bP1);
     }
@@ -823,6 +852,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
     for (int g = 0; g < ngroups; ++g) {
         const bool px = g + 1 < ngroups;
+        const int gn = g;                                        // the second stage loads the weights of group gn + 1
         const long xo = px ? patch_offset(g + 1) : 0;
         const int nb = (g + 1) & 1;
         const int xb = HQ_XBASE + (g & 1) * HQ_XB, xbn = HQ_XBASE + nb * HQ_XB;
@@ -835,51 +865,119 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
 
         // ======== first stage: taps (0,1) (2,3) [4] from weight buffer A
         LA(dwh, HQ_WA + aP);
-        pair(1, g, xo, nb, px, 0, HQ_WA, xb + bP1,
+        pair(1, g, gn, xo, nb, px, 0, HQ_WA, xb + bP1,
              [&] { LA(dwh, 2 * HQ_TAPU + HQ_WA + aP); LB(xl, xb + 2 + bP32 + HP_PL); },
              [&] { LB(xh, xb + 2 + bP32); });
-        pair(0, g, xo, nb, px, 2 * HQ_TAPU, HQ_WA, xb + 2 + bP32,
+        pair(0, g, gn, xo, nb, px, 2 * HQ_TAPU, HQ_WA, xb + 2 + bP32,
              [&] { LA(a1d, aS1 + HQ_WA); LB(b1x, bS1); },
              [&] { LA(a1w, aS1); });
         LA(a2, aS2);
-        NBE_SB; MM8(dc, a1d, b1x, 0, 0, g, xo, nb, px); NBE_SB;          // dwh.xl + dwl.xh
+        NBE_SB; MM8(dc, a1d, b1x, 0, 0, g, gn, xo, nb, px); NBE_SB;          // dwh.xl + dwl.xh
         LB(b2, bS2);
         {
             const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
             a0[0] = ks ? a2[0] : zero;                                   // [0 | wh]  (VALU, one product ahead of its MFMAs)
             a0[1] = ks ? a2[1] : zero;
         }
-        NBE_SB; MM8(yc, a1w, b1x, 0, 0, g, xo, nb, px); NBE_SB;          // wh.xl + wl.xh
+        NBE_SB; MM8(yc, a1w, b1x, 0, 0, g, gn, xo, nb, px); NBE_SB;          // wh.xl + wl.xh
         LB(b1d, bS1 + HQ_XT);
-        NBE_SB; MM8(ym, a0, b1x, 0, 0, g, xo, nb, px); NBE_SB;           // wh.xh
+        NBE_SB; MM8(ym, a0, b1x, 0, 0, g, gn, xo, nb, px); NBE_SB;           // wh.xh
         LB(xl, xb + SH5 + bP32 + HP_PL);                                 // x of taps (5,6): this group's patch
-        NBE_SB; MM8(dm, a2, b2, 0, 0, g, xo, nb, px); NBE_SB;            // dwh.xh + wh.dxh
+        NBE_SB; MM8(dm, a2, b2, 0, 0, g, gn, xo, nb, px); NBE_SB;            // dwh.xh + wh.dxh
         LB(xh, xb + SH5 + bP32);
-        NBE_SB; MM8(dc, a1w, b1d, 0, 0, g, xo, nb, px); NBE_SB;          // wh.dxl + wl.dxh
-        __syncthreads();                                         // buffer B and the x patch of g+1 have landed
+        NBE_SB; MM8(dc, a1w, b1d, 0, 0, g, gn, xo, nb, px); NBE_SB;          // wh.dxl + wl.dxh
+        NBE_STAGE_END(1, 0)                                      // buffer B and the x patch of g+1 have landed
 
         // ======== second stage: taps (5,6) (7,8) from weight buffer B
         LA(dwh, HQ_OFF_B + HQ_WB + aP);
-        pair(2, g, xo, nb, px, HQ_OFF_B, HQ_WB, xb + SH5 + bP32,
+        pair(2, g, gn, xo, nb, px, HQ_OFF_B, HQ_WB, xb + SH5 + bP32,
              [&] { LA(dwh, HQ_OFF_B + 2 * HQ_TAPU + HQ_WB + aP); LB(xl, xb + SH7 + bP1 + HP_PL); },
              [&] { LB(xh, xb + SH7 + bP1); });
-        pair(0, g, xo, nb, px, HQ_OFF_B + 2 * HQ_TAPU, HQ_WB, xb + SH7 + bP1,
+        pair(0, g, gn, xo, nb, px, HQ_OFF_B + 2 * HQ_TAPU, HQ_WB, xb + SH7 + bP1,
              [&] { if (px) LB(xl, xbn + bP1 + HP_PL); },         // x of taps (0,1) of the next group: landed above
              [&] { if (px) LB(xh, xbn + bP1); });
-        __syncthreads();                                         // buffer A and the dx patch of g+1 have landed
+        NBE_STAGE_END(4, 0)                                      // buffer A and both patches of g+1 have landed
     }
 #undef NBE_SB
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
 
-    // ---- epilogue: tile t = 4*mt + nt covers couts 32*it + 16*mt + 4*q .. +3 of position (2*jq + jt, 16*nh + c)
+    // ---- epilogue: tile t = 4*mt + nt covers couts 32*it + 16*mt + 4*q .. +3 of position (2*jq + jt, 16*nh + c).
+    // All global loads (bias, residuals of the 8 tiles) are issued before the first use: done tile by tile every
+    // store would be waited for by the next tile's loads (vmcnt counts both) -- 12 % of the kernel's wave cycles
+    // when it was written that way.  Out-of-range lanes load from a valid dummy address and skip the store.
+    {
+        const bool act = a.flags & F_ACT, res = a.flags & F_RES;
+        int unit[2];
+        bool uok[2];
+        f32x4 bv[2];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int mt = t >> 2, nt = t & 3;
-        const int yy = y0 + 2 * jq + (nt >> 1), xx = x0 + 16 * (nt & 1) + c;
-        if (yy >= a.Hv || xx >= a.Wv) continue;
-        const long o = ((long)z * a.Ho + yy) * a.Wo + xx;
-        h3_store16(a, ct * 8 + 4 * it + 2 * mt + ks, kh, o, ym[t], yc[t], dm[t], dc[t]);
+        for (int mt = 0; mt < 2; ++mt) {
+            unit[mt] = ct * 8 + 4 * it + 2 * mt + ks;
+            uok[mt] = unit[mt] < a.cout_groups;
+            if (!uok[mt]) unit[mt] = a.cout_groups - 1;
+            bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
+        }
+        long o[4];
+        bool ook[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int yy = y0 + 2 * jq + (nt >> 1), xx = x0 + 16 * (nt & 1) + c;
+            ook[nt] = yy < a.Hv && xx < a.Wv;
+            o[nt] = ook[nt] ? ((long)z * a.Ho + yy) * a.Wo + xx : (long)z * a.Ho * a.Wo;
+        }
+        half4 rh[8], rl[8], dh[8], dl[8];
+        if (res) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const long rb = ((long)(2 * unit[t >> 2]) * a.res_pstride + o[t & 3]) * 16 + 8 * kh;
+                const long rl_ = rb + a.res_pstride * 16;
+                rh[t] = *(const half4*)((const char*)a.r + rb);
+                rl[t] = *(const half4*)((const char*)a.r + rl_);
+                dh[t] = *(const half4*)((const char*)a.dr + rb);
+                dl[t] = *(const half4*)((const char*)a.dr + rl_);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int mt = t >> 2, nt = t & 3;
+            f32x4 v, dv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = ym[t][e] + yc[t][e] * H3_INV + bv[mt][e];
+                dv[e] = dm[t][e] + dc[t][e] * H3_INV;
+            }
+            if (res) { v += join4(rh[t], rl[t]); dv += join4(dh[t], dl[t]); }
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                    v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                }
+            }
+            if (uok[mt] && ook[nt]) {
+                const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + o[nt]) * 16 + 8 * kh;
+                const long ol = ob + a.out_pstride * 16;
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *(half4*)((char*)a.y + ob) = hi;
+                *(half4*)((char*)a.y + ol) = lo;
+                split4(dv, hi, lo);
+                *(half4*)((char*)a.dy + ob) = hi;
+                *(half4*)((char*)a.dy + ol) = lo;
+            }
+        }
     }
+#if NBE_DBG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NBE_STAMP(7)
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&h3q_stamps[i], tk[i]);
+        atomicAdd(&h3q_stamps[8], 1ull);
+    }
+#endif
+#undef NBE_STAMP
+#undef NBE_STAGE_END
 }
 
 // the activation DMA uses 32-bit per-lane offsets inside one 16-channel chunk (4 planes + one patch)

@@ -287,3 +287,9 @@ class Engine:
 
     def workspace_bytes(self):
         return int(self._l.nbe_workspace_bytes(self._h))
+
+    def debug_phase_cycles(self):
+        """Timing-probe builds only (NBE_BUILD_DBG=1): cycle totals per phase of the f16x3 3x3x3 kernel."""
+        out = (C.c_double * 16)()
+        check(self._l.nbe_debug_phase_cycles(self._h, out))
+        return list(out)
