@@ -169,11 +169,11 @@ def main():
         peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0, "f16": PEAK_F16_MFMA_TFLOPS}[precision]
         # HBM-side bytes per launch of the dominant kernel cannot be read from inside the process; they come from
         # the committed rocprofv3 --pmc passes of this exact workload (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # profiles/r01_pmc_fetch_write_default_f16x3.txt) and are reported only when the configuration matches.
+        # profiles/r01_pmc_fetch_write_default_q16.txt) and are reported only when the configuration matches.
         traffic = None
         if (precision, N, args.ndiv, args.max_tile, vel, world) == ("f16x3", 512, 4, 256, True, 1) \
                 and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
-            traffic = 26.96e9
+            traffic = 26.25e9
         return {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": traffic, "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                 "launches": dom["launches"], "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
