@@ -85,11 +85,19 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    # test rig: NBE_BENCH_ONE_GPU=1 runs all ranks on cuda:0 with gloo halos (RCCL refuses several ranks per device);
+    # the numbers of such a run mean nothing, it only exercises the N > 1 code path on a one-GPU box
+    one_gpu = os.environ.get("NBE_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     vel = not args.no_vel
     model = (StyleNBodyEmulatorVelCore if vel else StyleNBodyEmulatorCore)()
