@@ -7,7 +7,8 @@ ndiv=(4,4,4), StyleNBodyEmulatorVelCore, float32, on N MI355X of one node.
          bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of process_box over the whole box (64 sub-boxes of 224^3 -> 128^3, which the engine
-merges into 8 tiles of 352^3 -> 256^3 when that is exact; --max-tile 0 disables it), with the input box and
+merges into the largest tiles whose workspace fits the card -- two of 352x608x608 -> 256x512x512 on a free
+288 GB MI355X -- when that is exact; --max-tile 256 / 0 restrict it to 256^3 tiles / disable it), with the input box and
 the output boxes resident in HBM.  Arithmetic: float32-equivalent f16x3 split MFMA by default (`value`); the
 strict float32 MFMA path is timed on the same box and reported under "strict_f32".  Weights are synthetic (seeded; the pretrained blob is not
 available), which changes neither the FLOPs nor the bytes.  Rank 0 prints ONE JSON line.
@@ -60,9 +61,10 @@ def main():
     ap.add_argument("--ndiv", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vel", action="store_true")
-    ap.add_argument("--max-tile", type=int, default=256,
-                    help="internal tile edge: sub-boxes are merged into tiles up to this size when that is exact "
-                         "(crop %% 8 == 0); 0 = run the caller's 64 sub-boxes of 224^3 one by one")
+    ap.add_argument("--max-tile", type=int, default=512,
+                    help="cap on the internal tile edge: sub-boxes are merged into the largest tile that fits the "
+                         "card's free memory when that is exact (crop %% 8 == 0): 512 -> four tiles of 256x256x512, "
+                         "256 -> eight of 256^3; 0 = run the caller's 64 sub-boxes of 224^3 one by one")
     ap.add_argument("--precision", default=os.environ.get("NBE_PRECISION", "f16x3"), choices=["f32", "f16x3", "f16"],
                     help="f16x3 (default): float32-equivalent split-f16 MFMA, 3 MFMAs per product, f32 accumulate, "
                          "whole-network error vs the float64 oracle equal to or below the strict path's; "

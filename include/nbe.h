@@ -110,10 +110,15 @@ int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3],
  * phase of the network's 2^3 stride lattice, so the per-voxel result does not depend on how the box is cut
  *  and neighbouring sub-boxes can be merged into larger tiles that recompute less halo
  * (17.1 MFLOP/voxel at 128^3 crops, 11.2 at 256^3).  nbe_plan_tiles returns the grid nbe_process_box will
- * actually run: per axis the largest merge with tile edge <= max_tile; unchanged when crop % 8 != 0.
- * nbe_set_max_tile(ctx, 0) keeps the caller's grid exactly (default 256, or env NBE_MAX_TILE). */
+ * with a cubic cap: per axis the largest merge with tile edge <= max_tile; unchanged when crop % 8 != 0.
+ * nbe_set_max_tile(ctx, 0) keeps the caller's grid exactly; nbe_set_max_tile(ctx, 256) restricts to 256^3 tiles. */
 int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int out_ndiv[3]);
 int nbe_set_max_tile(nbe_ctx* ctx, int max_tile);
+/* The grid a context will actually run (weights loaded): among all exact merges with tile edge <= its max_tile
+ * (default 512, or env NBE_MAX_TILE) the one with the largest tile whose workspace fits the device memory free at
+ * the time of the call, longest along the last axis on ties (512^3 / ndiv 4 on a 288 GB MI355X: four tiles of
+ * 256 x 256 x 512).  Falls back to the caller's grid when merging is not exact or no weights are loaded. */
+int nbe_plan_tiles_ctx(nbe_ctx* ctx, const int64_t region[3], const int ndiv[3], int out_ndiv[3]);
 
 /* growth_factor / vel_norm (cosmology.py:34-40, :130-141) in double precision on the host. */
 double nbe_growth_factor(double z, double Om);

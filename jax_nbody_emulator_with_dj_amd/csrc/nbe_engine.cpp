@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -92,7 +93,7 @@ struct nbe_ctx {
     char* ws = nullptr;
     int64_t ws_bytes = 0;
     bool dry = false;
-    int max_tile = 256;                           // internal tile edge (output voxels); 0 = caller's grid as given
+    int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     // device-resident boxes of process_box
     float* box_in = nullptr; int64_t box_in_bytes = 0;
@@ -365,15 +366,20 @@ static int network(nbe_ctx* c, const Tensor& tin, Tensor* yout) {
     return 0;
 }
 
-// size the workspace for a (D,H,W) input with a dry run, then (re)allocate it
-static int ensure_workspace(nbe_ctx* c, int D, int H, int W) {
+// bytes of workspace a (D,H,W) input needs: a dry run of the network through the arena (no launches); < 0 on error
+static int64_t workspace_need(nbe_ctx* c, int D, int H, int W) {
     c->dry = true;
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
-    int rc = network(c, tin, &y);
+    const int rc = network(c, tin, &y);
     c->dry = false;
-    if (rc) return rc;
-    const int64_t need = c->arena.high;
+    return rc ? -1 : c->arena.high;
+}
+
+// size the workspace for a (D,H,W) input with a dry run, then (re)allocate it
+static int ensure_workspace(nbe_ctx* c, int D, int H, int W) {
+    const int64_t need = workspace_need(c, D, H, W);
+    if (need < 0) return 1;
     if (need > c->ws_bytes) {
         if (c->ws) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
         HIPCHK(hipMalloc((void**)&c->ws, need));
@@ -668,6 +674,50 @@ int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int
     return 0;
 }
 
+// The grid process_region will run: among all merges of the caller's sub-boxes (exact only when crop % 8 == 0 on
+// every axis) with tile edge <= max_tile, the one with the largest tile volume whose workspace fits the device
+// memory that is free now (plus what this context already holds, minus `reserve`); ties go to the tile that is
+// longest along the last (fastest) axis.  512^3 / ndiv 4 on a 288 GB MI355X: four tiles of 256 x 256 x 512
+// (input 352 x 352 x 608, a ~175 GB workspace), 12 % fewer FLOPs than eight tiles of 256^3.
+static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int64_t reserve, int out_ndiv[3]) {
+    for (int a = 0; a < 3; ++a) out_ndiv[a] = ndiv[a];
+    if (c->max_tile <= 0 || !c->have_weights) return 0;
+    int64_t crop[3];
+    for (int a = 0; a < 3; ++a) {
+        if (ndiv[a] < 1 || region[a] < 1) return fail("sizes and ndiv must be positive");
+        crop[a] = region[a] / ndiv[a];
+        if (crop[a] % 8 != 0 || crop[a] * ndiv[a] != region[a]) return 0;      // merging would not be exact
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int64_t budget = (int64_t)free_b + c->ws_bytes - reserve - ((int64_t)3 << 30);
+    int64_t best_vol = 0, best_w = 0;
+    for (int m0 = 1; m0 <= ndiv[0]; ++m0) {
+        if (ndiv[0] % m0 || crop[0] * m0 > c->max_tile) continue;
+        for (int m1 = 1; m1 <= ndiv[1]; ++m1) {
+            if (ndiv[1] % m1 || crop[1] * m1 > c->max_tile) continue;
+            for (int m2 = 1; m2 <= ndiv[2]; ++m2) {
+                if (ndiv[2] % m2 || crop[2] * m2 > c->max_tile) continue;
+                const int64_t e0 = crop[0] * m0, e1 = crop[1] * m1, e2 = crop[2] * m2, vol = e0 * e1 * e2;
+                const int64_t w = e2 * 1000000 + e1 * 1000 + e0;               // tie-break: long last axis
+                if (vol < best_vol || (vol == best_vol && w <= best_w)) continue;
+                if (check_dims((int)e0 + 96, (int)e1 + 96, (int)e2 + 96)) { (void)nbe_last_error(); continue; }
+                const int64_t need = workspace_need(c, (int)e0 + 96, (int)e1 + 96, (int)e2 + 96);
+                if (need < 0 || need > budget) continue;
+                best_vol = vol; best_w = w;
+                out_ndiv[0] = ndiv[0] / m0; out_ndiv[1] = ndiv[1] / m1; out_ndiv[2] = ndiv[2] / m2;
+            }
+        }
+    }
+    return 0;
+}
+
+int nbe_plan_tiles_ctx(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int out_ndiv[3]) {
+    if (!c || !region || !ndiv || !out_ndiv) return fail("null argument");
+    HIPCHK(hipSetDevice(c->device));
+    return plan_tiles_mem(c, region, ndiv, 0, out_ndiv);
+}
+
 int nbe_set_precision(nbe_ctx* c, int prec) {
     if (!c) return fail("null context");
     if (prec != PREC_F32 && prec != PREC_F16X3 && prec != PREC_F16) return fail("precision must be NBE_PREC_F32 (0), NBE_PREC_F16X3 (1) or NBE_PREC_F16 (2)");
@@ -702,11 +752,21 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     // sub-boxes may be merged into larger tiles (nbe_plan_tiles) -- identical results, less halo recompute.
     int ndiv_eff[3] = {ndiv_in[0], ndiv_in[1], ndiv_in[2]};
     if (!order && c->max_tile > 0) {
-        if (nbe_plan_tiles(region, ndiv_in, c->max_tile, ndiv_eff)) return 1;
-        // fall back to the caller's grid when the merged tile's workspace cannot be allocated
-        if (ndiv_eff[0] != ndiv_in[0] || ndiv_eff[1] != ndiv_in[1] || ndiv_eff[2] != ndiv_in[2]) {
+        HIPCHK(hipSetDevice(c->device));
+        // host arrays in / out are staged in device buffers that are allocated below: keep room for them
+        const int64_t in_b = (int64_t)S0 * S1 * S2 * c->in_chan * 4;
+        const int64_t out_b = (int64_t)O0 * O1 * O2 * c->out_chan * (out_dtype == NBE_F16 ? 2 : 4) * (c->vel ? 2 : 1);
+        const int64_t reserve = (is_device_ptr(box) ? 0 : std::max<int64_t>(0, in_b - c->box_in_bytes)) +
+                                (is_device_ptr(disp) ? 0 : std::max<int64_t>(0, out_b - c->box_out_bytes));
+        if (plan_tiles_mem(c, region, ndiv_in, reserve, ndiv_eff)) return 1;
+        // fall back to cubic tiles <= 256, then to the caller's grid, when the workspace cannot be allocated after all
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (ndiv_eff[0] == ndiv_in[0] && ndiv_eff[1] == ndiv_in[1] && ndiv_eff[2] == ndiv_in[2]) break;
             const int d = (int)(region[0] / ndiv_eff[0]) + 96, h = (int)(region[1] / ndiv_eff[1]) + 96, w = (int)(region[2] / ndiv_eff[2]) + 96;
-            if (ensure_workspace(c, d, h, w)) { ndiv_eff[0] = ndiv_in[0]; ndiv_eff[1] = ndiv_in[1]; ndiv_eff[2] = ndiv_in[2]; (void)hipGetLastError(); }
+            if (!ensure_workspace(c, d, h, w)) break;
+            (void)hipGetLastError();
+            if (attempt == 0 && c->max_tile > 256) { if (nbe_plan_tiles(region, ndiv_in, 256, ndiv_eff)) return 1; }
+            else { ndiv_eff[0] = ndiv_in[0]; ndiv_eff[1] = ndiv_in[1]; ndiv_eff[2] = ndiv_in[2]; }
         }
     }
     const int* ndiv = ndiv_eff;

@@ -668,7 +668,6 @@ constexpr int HQ_XT = 4 * HP_PL;                          // units of one tensor
 constexpr int HQ_XB = 2 * HQ_XT;                          // one patch buffer: X, dX
 constexpr int HQ_XBASE = HQ_OFF_B + 2 * HQ_WB;
 constexpr int HQ_LDS_UNITS = HQ_XBASE + 2 * HQ_XB;        // 10048 units = 160,768 B
-constexpr int HQ_NX = (HQ_XT + 63) / 64;                  // DMA instructions per tensor patch: 22 (the last one partial)
 
 // global -> LDS DMA with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit per-lane pointers
 __device__ __forceinline__ void dma16s(const char* ubase, unsigned voff, f32x4* dst_wave_base) {
@@ -738,27 +737,28 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         dma16s((const char*)(set ? a.dw : a.w) + src * 16, lane16,
                lds + (second ? HQ_OFF_B : 0) + set * (second ? HQ_WB : HQ_WA) + m * 64);
     };
-    unsigned xoff[3];                                            // < 2^32: checked by the launcher
+    // Patch DMA: 6 wave-instructions per plane of 340 units (the 6th covers 20 lanes), 24 per tensor, 3 per wave;
+    // the plane goes into the uniform base, the per-lane offset is the position inside the plane (32 bits).
+    unsigned xoff[3];
     bool xval[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int n = wave + 8 * t;
-        const int u = n * 64 + lane;
-        xval[t] = n < HQ_NX && u < HQ_XT;
-        const int uu = u < HQ_XT ? u : HQ_XT - 1;
-        const int pl = uu / HP_PL, rem = uu - pl * HP_PL;
-        const int row = rem / HP_RS, col = rem - row * HP_RS;
-        xoff[t] = (unsigned)(((long)pl * a.in_pstride + (long)row * a.W + col) * 16);
+        const int k = (wave + 8 * t) % 6;
+        const int u = k * 64 + lane;
+        xval[t] = u < HP_PL;
+        const int uu = xval[t] ? u : HP_PL - 1;
+        const int row = uu / HP_RS, col = uu - row * HP_RS;
+        xoff[t] = (unsigned)(row * a.W + col) * 16u;
     }
     auto patch_offset = [&](int g) -> long {                     // g = chunk*3 + dz
         const int chunk = g / 3, dz = g - chunk * 3;
         return ((long)chunk * 4 * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
     };
     auto dma_x = [&](int tensor, int t, long xo, int buf) {
-        const int n = wave + 8 * t;
-        if (n < HQ_NX && xval[t])
-            dma16s((const char*)(tensor ? a.dx : a.x) + xo, xoff[t],
-                   lds + HQ_XBASE + buf * HQ_XB + tensor * HQ_XT + n * 64);
+        const int n = wave + 8 * t, pl = n / 6, k = n - 6 * pl;
+        if (xval[t])
+            dma16s((const char*)(tensor ? a.dx : a.x) + xo + (long)pl * a.in_pstride * 16, xoff[t],
+                   lds + HQ_XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HP_PL + k * 64);
     };
 
     f32x4 ym[8], yc[8], dm[8], dc[8];
@@ -980,11 +980,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
 #undef NBE_STAGE_END
 }
 
-// the activation DMA uses 32-bit per-lane offsets inside one 16-channel chunk (4 planes + one patch)
-static bool h3q_fits(const ConvKArgs& ka) {
-    return (4 * ka.in_pstride + (long)(HP_ROWS + 2) * ka.W + HP_RS) * 16 < (1L << 32);
-}
-
 static void launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
     constexpr size_t smem = (size_t)HQ_LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
@@ -1051,7 +1046,7 @@ void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_d
     else F<__VA_ARGS__, false, false>(ka, ct, s);
     static const bool shape32 = getenv("NBE_H3_SHAPE") && atoi(getenv("NBE_H3_SHAPE")) == 32;   // A/B: 32x32x16 MFMAs
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
-        if (split && vel && has_dx && !shape32 && sched == 0 && h3q_fits(ka)) { launch_h3q(ka, ct, s); return; }
+        if (split && vel && has_dx && !shape32 && sched == 0) { launch_h3q(ka, ct, s); return; }
         if (!split) { NBE_VD(launch_h3p_v, 0, false) }
         else if (sched == 1) { NBE_VD(launch_h3p_v, 1, true) }
         else { NBE_VD(launch_h3p_v, 0, true) }

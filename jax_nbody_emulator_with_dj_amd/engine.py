@@ -148,14 +148,11 @@ class Engine:
         self.max_tile = int(max_tile)
 
     def plan_tiles(self, region, ndiv):
-        """The sub-box grid the engine will actually run for `region` cut by `ndiv` (nbe_plan_tiles)."""
-        import os
-        mt = getattr(self, 'max_tile', None)
-        if mt is None:
-            mt = int(os.environ.get("NBE_MAX_TILE", "256"))
+        """The sub-box grid the engine will actually run for `region` cut by `ndiv` (nbe_plan_tiles_ctx): the
+        largest exact merge whose workspace fits the free device memory."""
         out = (C.c_int * 3)()
-        check(self._l.nbe_plan_tiles((C.c_int64 * 3)(*[int(r) for r in region]), (C.c_int * 3)(*[int(n) for n in ndiv]),
-                                     max(mt, 0), out))
+        check(self._l.nbe_plan_tiles_ctx(self._h, (C.c_int64 * 3)(*[int(r) for r in region]),
+                                         (C.c_int * 3)(*[int(n) for n in ndiv]), out))
         return tuple(out)
 
     def synchronize(self):

@@ -112,7 +112,7 @@ def test_process_box_float16_model():
     try:
         dis0, vel0 = emu.process_box(box, Z, OM, show_progress=False)
     finally:
-        eng.set_max_tile(256)
+        eng.set_max_tile(512)
     # same per-voxel arithmetic; float32 sums may differ in the last bit and flip a float16 rounding
     assert rel_l2(dis, dis0) <= 1e-3 and rel_l2(vel, vel0) <= 1e-2
 
@@ -197,7 +197,12 @@ def test_internal_tile_merging_is_exact():
     m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
     p = _synthetic(13, 8)
     eng = get_engine(m, 0)
-    assert eng.plan_tiles((512,) * 3, (4,) * 3) == (2, 2, 2)
+    eng.ensure_params(p, False)                                 # the plan sizes the workspace by a dry run of the network
+    eng.set_max_tile(256)
+    assert eng.plan_tiles((512,) * 3, (4,) * 3) == (2, 2, 2)                # cubic cap: 256^3 tiles
+    eng.set_max_tile(512)
+    t = eng.plan_tiles((512,) * 3, (4,) * 3)                                # memory-aware: the largest tile that fits
+    assert all(4 % n == 0 for n in t) and int(np.prod(t)) <= 8, t
     assert eng.plan_tiles((32, 16, 16), (4, 2, 2)) == (1, 1, 1)
     assert eng.plan_tiles((36, 16, 16), (3, 2, 2)) == (3, 2, 2)           # crop 12: lattice phase would change
     size, ndiv = (32, 16, 16), (4, 2, 2)
@@ -206,18 +211,18 @@ def test_internal_tile_merging_is_exact():
     try:
         eng.set_max_tile(0)
         d0, v0 = proc.process_box(box, Z, OM, show_progress=False)
-        eng.set_max_tile(256)
+        eng.set_max_tile(512)
         d1, v1 = proc.process_box(box, Z, OM, show_progress=False)
     finally:
-        eng.set_max_tile(256)
+        eng.set_max_tile(512)
     _close(d1, d0, 1e-6, 1e-5, "merged tiles disp")
     _close(v1, v0, 1e-6, 1e-5, "merged tiles vel")
 
 
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():
     """BASELINE config 3: 512^3 box, ndiv=(4,4,4), compute_vel=True, production width, resident tensors.
-    Size-independent property: the engine's default execution (8 merged tiles of 352^3 input) and the
-    caller's grid run exactly (64 sub-boxes of 224^3) give the same fields; plus velocity proportional to
+    Size-independent property: the engine's default execution (merged tiles: four of 352 x 352 x 608 input when
+    the card's memory is free, eight of 352^3 otherwise) and the caller's grid run exactly (64 sub-boxes of 224^3) give the same fields; plus velocity proportional to
     vel_fac through the whole sub-box loop."""
     import torch
     from jax_nbody_emulator_with_dj_amd.models import get_engine
@@ -231,7 +236,9 @@ def test_config3_at_full_size_merged_tiles_vs_callers_grid():
     eng.ensure_params(p, False)
     Dz, vf = float(J.growth_factor(Z, OM)), float(J.vel_norm(Z, OM))
     eng.set_cosmology(OM, Dz)
-    assert eng.plan_tiles(size, ndiv) == (2, 2, 2)
+    plan = eng.plan_tiles(size, ndiv)          # 288 GB free: (2, 2, 1) = four tiles of 256 x 256 x 512
+    print("config 3 internal tiles:", plan)
+    assert all(4 % n == 0 for n in plan) and int(np.prod(plan)) <= 8, plan
     pad = ((48, 48),) * 3
     d1, v1 = eng.process_box(box, size, ndiv, pad, Dz, vf)
     try:
@@ -239,7 +246,7 @@ def test_config3_at_full_size_merged_tiles_vs_callers_grid():
         assert eng.plan_tiles(size, ndiv) == (4, 4, 4)
         d0, v0 = eng.process_box(box, size, ndiv, pad, Dz, 2.0 * vf)
     finally:
-        eng.set_max_tile(256)
+        eng.set_max_tile(512)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(d1).all()) and bool(torch.isfinite(v1).all())
     rms_d, rms_v = float(d1.pow(2).mean().sqrt()), float(v1.pow(2).mean().sqrt())

@@ -46,7 +46,7 @@ def test_asymmetric_divisions_noncubic_crops():
         eng.set_max_tile(0)
         dis0, vel0 = emu.process_box(box, z, Om, show_progress=False)
     finally:
-        eng.set_max_tile(256)
+        eng.set_max_tile(512)
     _close(dis0, GOLD["asym_disp"], 2e-5, 2e-4, "asymmetric disp, caller's grid")
     _close(vel0, GOLD["asym_vel"], 5e-5, 2e-4, "asymmetric vel, caller's grid")
 
