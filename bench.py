@@ -169,7 +169,7 @@ def main():
         eng.close()
         return dt, prof, ok, plan
 
-    def roofline(prof, precision):
+    def roofline(prof, precision, plan=""):
         # dominant kernel, from HIP events recorded on the engine's stream inside the timed region.
         # f16x3 issues three f16 MFMAs per float32 product: algorithmic FLOPs are priced against 1/3 of the
         # dense f16 MFMA peak (2.5 PFLOP/s).
@@ -179,11 +179,13 @@ def main():
         peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0, "f16": PEAK_F16_MFMA_TFLOPS}[precision]
         # HBM-side bytes per launch of the dominant kernel cannot be read from inside the process; they come from
         # the committed rocprofv3 --pmc passes of this exact workload (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # profiles/r01_pmc_fetch_write_default_q16.txt) and are reported only when the configuration matches.
+        # see the file named beside each value) and are reported only when the configuration matches.
         traffic = None
-        if (precision, N, args.ndiv, args.max_tile, vel, world) == ("f16x3", 512, 4, 256, True, 1) \
-                and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
-            traffic = 26.25e9
+        if (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
+            if plan.startswith("(2, 1, 1)"):
+                traffic = 89.0e9            # profiles/r01_pmc_fetch_write_default_tiles211.txt
+            elif plan.startswith("(2, 2, 2)"):
+                traffic = 26.25e9           # profiles/r01_pmc_fetch_write_default_q16.txt
         return {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": traffic, "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                 "launches": dom["launches"], "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
@@ -209,7 +211,7 @@ def main():
             "finite": ok,
         }
         if prof:
-            out["roofline"] = roofline(prof, args.precision)
+            out["roofline"] = roofline(prof, args.precision, plan)
             out["kernels"] = [{"kernel": e["kernel"], "ms": round(e["ms"], 3), "launches": e["launches"],
                                "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
                               for e in sorted(prof, key=lambda e: -e["ms"])]
