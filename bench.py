@@ -92,6 +92,7 @@ def main():
     one_gpu = os.environ.get("NBE_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+        os.environ.setdefault("NBE_MEM_FRACTION", "%.3f" % (0.8 / max(world, 1)))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -690,7 +690,10 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
     }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const int64_t budget = (int64_t)free_b + c->ws_bytes - reserve - ((int64_t)3 << 30);
+    // NBE_MEM_FRACTION (default 1): share of the free memory this context may plan with -- for rigs that run several
+    // ranks on one card, where every rank sees the same free memory at the same time
+    static const double frac = getenv("NBE_MEM_FRACTION") ? std::min(1.0, std::max(0.01, atof(getenv("NBE_MEM_FRACTION")))) : 1.0;
+    const int64_t budget = (int64_t)(((double)free_b + (double)c->ws_bytes) * frac) - reserve - ((int64_t)3 << 30);
     int64_t best_vol = 0, best_w = 0;
     for (int m0 = 1; m0 <= ndiv[0]; ++m0) {
         if (ndiv[0] % m0 || crop[0] * m0 > c->max_tile) continue;

@@ -36,6 +36,18 @@ def engine_factory():
         e.close()
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _release_cached_engines():
+    """The API shim caches one engine per (device, architecture, arithmetic) with its workspace -- up to ~276 GB after a
+    full-size box.  Hand the card back after every test module so that later tests plan their tiles on a free card."""
+    yield
+    try:
+        from jax_nbody_emulator_with_dj_amd import models
+        models.release_engines()
+    except Exception:
+        pass
+
+
 def rel_l2(a, b):
     import numpy as np
     a = np.asarray(a, dtype=np.float64)

@@ -28,6 +28,7 @@ def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["NBE_MEM_FRACTION"] = "%.3f" % (0.8 / world)     # the ranks share one card: plan tiles with a share of it
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import jax_nbody_emulator_with_dj_amd as J
@@ -60,6 +61,7 @@ def test_sharded_equals_single_process(world, size, ndiv):
     import torch.multiprocessing as mp
     import jax_nbody_emulator_with_dj_amd as J
     from oracle import params as P
+    J.models.release_engines()                                  # give the card back before the rank processes start
     seed_p, seed_x = 61, 62
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -67,7 +69,7 @@ def test_sharded_equals_single_process(world, size, ndiv):
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, size, ndiv, seed_p, seed_x, q)) for r in range(world)]
     for pr in procs:
         pr.start()
-    parts = [q.get(timeout=300) for _ in range(world)]
+    parts = [q.get(timeout=120) for _ in range(world)]
     for pr in procs:
         pr.join(timeout=120)
         assert pr.exitcode == 0
