@@ -250,10 +250,11 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
     if (!Ls || !L0 || !L1) return fail("missing layers of block %s", name);
     const int D = x.p.D, H = x.p.H, W = x.p.W;
+    // The second convolution adds the skip as a residual and writes its result over it (every lane reads its residual
+    // elements before it stores the same elements): one full-resolution tensor pair less at the workspace peak.
     Tensor s = talloc(c, cout, D - 4, H - 4, W - 4);
     Tensor h = talloc(c, cmid, D - 2, H - 2, W - 2);
-    Tensor o = talloc(c, cout, D - 4, H - 4, W - 4);
-    if (s.off < 0 || h.off < 0 || o.off < 0) return fail("workspace exhausted in block %s", name);
+    if (s.off < 0 || h.off < 0) return fail("workspace exhausted in block %s", name);
     {
         ConvLaunch cl; cl.in = x.p; cl.in_off = (2L * H + 2) * W + 2;
         cl.Dv = D - 4; cl.Hv = H - 4; cl.Wv = W - 4; cl.out = s.p; cl.flags = 0;
@@ -264,12 +265,12 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
         run_conv(c, *L0, cl, has_dx);
     }
     {
-        ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = H - 4; cl.Wv = W - 4; cl.out = o.p;
+        ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = H - 4; cl.Wv = W - 4; cl.out = s.p;
         cl.res = s.p; cl.flags = F_RES | (final_act ? F_ACT : 0);
         run_conv(c, *L1, cl, true);
     }
-    tfree(c, s); tfree(c, h);
-    *out = o;
+    tfree(c, h);
+    *out = s;
     return 0;
 }
 
