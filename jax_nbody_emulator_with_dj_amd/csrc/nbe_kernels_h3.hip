@@ -995,6 +995,292 @@ static void launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
     hipLaunchKernelGGL(conv_h3q_kernel, grid, block, smem, s, ka);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The two-accumulator variants on the 16x16x32 shape: f16x3 without velocity and plain f16 with velocity
+// ------------------------------------------------------------------------------------------------
+// Both have one product for the first accumulator set and two for the second:
+//   SPLIT  (f16x3, displacement only): a0 = w hi, a1 = w lo, b0 = x hi, b1 = x lo:  ym += a0.b0, yc += a0.b1 + a1.b0
+//   !SPLIT (f16, velocity):            a0 = w,    a1 = dw,   b0 = x,    b1 = dx:    ym += a0.b0, dm += a0.b1 + a1.b0
+// so one kernel serves both; what differs is where a1 and b1 live (the lo part / the tangent tensor) and the epilogue.
+// With half the accumulators of conv_h3q_kernel the workgroup tile doubles to 64 couts x 512 positions (16 rows x 32
+// columns of one plane): per MFMA the same bytes of weights and activations as there, instead of 1.5 x as many in the
+// 32x32x16 patch kernel, which left these two modes bound by the L2 -> LDS stream (0.35 of their peaks).
+// K = 32 is two taps x 16 channels as in conv_h3q_kernel; the single tap of a group pairs a0/a1 with b1/b0:
+// acc1 += [a0|a1].[b1|b0] and acc0 += [0|a0].[b1|b0].  Wave tile 32 couts x 128 positions (4 rows) = 2 x 8 MFMA tiles,
+// tile t = 8*mt + nt, nt = 2*row + column half; the rolling operand pipeline works on half tiles (2 rows).
+// LDS: weight buffer A (taps 0-4) / B (taps 5-8) with rows [tap][r][64 couts], r = 2*h + part (SPLIT) or 2*set + h;
+// patch planes p = 2*h + part (SPLIT) or 2*tensor + h, 18 x 34 units each.
+constexpr int H2_ROWS = 16;
+constexpr int H2_PL = (H2_ROWS + 2) * HP_RS;              // units per patch plane: 612
+constexpr int H2_XB = 4 * H2_PL;                          // one patch buffer: 4 planes
+constexpr int H2_TAPU = 4 * 64;                           // units per tap (all rows)
+constexpr int H2_WA = 5 * H2_TAPU, H2_WB = 4 * H2_TAPU;
+constexpr int H2_OFF_B = H2_WA;
+constexpr int H2_XBASE = H2_WA + H2_WB;
+constexpr int H2_LDS_UNITS = H2_XBASE + 2 * H2_XB;        // 7200 units = 115,200 B
+constexpr int H2_NPI = (H2_PL + 63) / 64;                 // DMA instructions per patch plane: 10 (the last one 36 lanes)
+
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
+    f32x4* lds = lds_h3;
+    const half8* L8 = (const half8*)lds_h3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
+    const int it = wave & 1, jq = wave >> 1;
+
+    const int tile = xcd_tile(blockIdx.x, a.ntiles);             // (ty, tx, z), z fastest
+    const int ct = blockIdx.y;
+    const int z = tile % a.Dv, tyx = tile / a.Dv;
+    const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
+    const int y0 = ty * H2_ROWS, x0 = tx * HP_COLS;
+    const int ngroups = 3 * a.nchunk;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    // ---- DMA.  Weight rows: instruction n = wave + 8t of a stage covers (tap, r) = (n / 4, n % 4).
+    auto dma_w = [&](int g, int second, int t) {
+        const int n = wave + 8 * t;
+        if (n >= (second ? 16 : 20)) return;
+        const int tap = (second ? 5 : 0) + (n >> 2), r = n & 3;
+        const char* src;
+        if (SPLIT) {
+            src = (const char*)a.w + (((long)ct * ngroups + g) * 9 * 4 + tap * 4 + r) * 64 * 16;
+        } else {
+            src = (const char*)((r >> 1) ? a.dw : a.w) + (((long)ct * ngroups + g) * 9 * 2 + tap * 2 + (r & 1)) * 64 * 16;
+        }
+        dma16s(src, lane16, lds + (second ? H2_OFF_B : 0) + n * 64);
+    };
+    // Patch: 10 instructions per plane, instruction n = wave + 8t (t < 5) -> plane n / 10, piece n % 10
+    unsigned xoff[5];
+    bool xval[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int k = (wave + 8 * t) % H2_NPI;
+        const int u = k * 64 + lane;
+        xval[t] = u < H2_PL;
+        const int uu = xval[t] ? u : H2_PL - 1;
+        const int row = uu / HP_RS, col = uu - row * HP_RS;
+        xoff[t] = (unsigned)(row * a.W + col) * 16u;
+    }
+    auto patch_offset = [&](int g) -> long {                     // g = chunk*3 + dz
+        const int chunk = g / 3, dz = g - chunk * 3;
+        return ((long)chunk * (SPLIT ? 4 : 2) * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
+    };
+    auto dma_x = [&](int t, long xo, int buf) {
+        const int n = wave + 8 * t, pl = n / H2_NPI, k = n - H2_NPI * pl;
+        if (xval[t]) {
+            const char* base = SPLIT ? (const char*)a.x + (long)pl * a.in_pstride * 16
+                                     : (const char*)((pl >> 1) ? a.dx : a.x) + (long)(pl & 1) * a.in_pstride * 16;
+            dma16s(base + xo, xoff[t], lds + H2_XBASE + buf * H2_XB + pl * H2_PL + k * 64);
+        }
+    };
+
+    f32x4 acc0[16], acc1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc0[t][e] = 0.f; acc1[t][e] = 0.f; }
+    auto mm = [&](f32x4& acc, const half8& A, const half8& B) {   // accumulators pinned in AGPRs, updated in place
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+    };
+
+    // ---- operands
+    constexpr int A1OFF = SPLIT ? 64 : 128;                      // a1 = a0 + one row (lo part) / two rows (dw set)
+    constexpr int B1OFF = SPLIT ? H2_PL : 2 * H2_PL;             // b1 = b0 + one plane (lo part) / two planes (dx tensor)
+    const int rowA = SPLIT ? 2 * kh : kh;
+    const int aP = (ks * 4 + rowA) * 64 + 32 * it + c;           // pair: tap ks of the pair, row of a0
+    const int bB = rowA * H2_PL + (4 * jq) * HP_RS + c;          // plane of b0 (same index rule as the weight row)
+    const int bP1 = bB + ks, bP32 = bB + 32 * ks;
+    auto LA = [&](half8 (&r)[2], int idx) {
+        r[0] = L8[idx];
+        r[1] = L8[idx + 16];
+    };
+    // B operands of one half tile (rows 2*hf, 2*hf + 1): 4 column tiles
+    auto LB = [&](half8 (&r)[4], int idx, int hf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = L8[idx + (2 * hf + (j >> 1)) * HP_RS + 16 * (j & 1)];
+    };
+    // one product on one half tile: 8 MFMAs on tiles t = 8*mt + 4*hf + j; kind 1 / 2: DMA slots `slot`, `slot + 1`
+    auto MM8 = [&](f32x4 (&acc)[16], const half8 (&A)[2], const half8 (&B)[4], int hf, int kind, int slot, int g,
+                   int gn, long xo, int nb, bool px) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mm(acc[8 * (i >> 2) + 4 * hf + (i & 3)], A[i >> 2], B[i & 3]);
+            if (kind != 0 && (i & 3) == 3) {
+                const int k = slot + (i >> 2);
+                if (kind == 1) {                                 // first stage: weights of the second, patch pieces 0-2
+                    if (k < 2) dma_w(g, 1, k);
+                    else if (k < 5 && px) dma_x(k - 2, xo, nb);
+                } else if (px) {                                 // second stage: weights of the next group, pieces 3-4
+                    if (k < 3) dma_w(gn + 1, 0, k);
+                    else if (k < 5) dma_x(k, xo, nb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#define NBE_SB __builtin_amdgcn_sched_barrier(0)
+    half8 a0x[2], a0y[2], a1[2], b1[4], b0a[4], b0b[4];
+    // A tap pair on both half tiles: six products; every operand is requested two products before its first use and
+    // at most 64 operand registers are alive.  On entry a0 (A0), b1 and b0a of the first half are loaded or in
+    // flight; pre5 / pre6 request those of whatever follows (a0 and b1 in pre5, b0a in pre6).
+    auto pair = [&](half8 (&A0)[2], int kind, int g, int gn, long xo, int nb, bool px, int wa, int xp,
+                    auto&& pre5, auto&& pre6) {
+        LA(a1, wa + A1OFF + aP);
+        NBE_SB; MM8(acc1, A0, b1, 0, kind, 0, g, gn, xo, nb, px); NBE_SB;      // a0.b1, first half
+        LB(b1, xp + B1OFF, 1);
+        NBE_SB; MM8(acc0, A0, b0a, 0, kind, 2, g, gn, xo, nb, px); NBE_SB;     // a0.b0
+        LB(b0b, xp, 1);
+        NBE_SB; MM8(acc1, a1, b0a, 0, kind, 4, g, gn, xo, nb, px); NBE_SB;     // a1.b0
+        MM8(acc1, A0, b1, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;                 // second half
+        pre5();
+        NBE_SB; MM8(acc0, A0, b0b, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
+        pre6();
+        NBE_SB; MM8(acc1, a1, b0b, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
+    };
+
+    // ---- prologue: the patch of group 0 and the weights of its first stage
+    {
+        const long x0off = patch_offset(0);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) dma_x(t, x0off, 0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) dma_w(0, 0, t);
+        __syncthreads();
+    }
+
+    constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;
+    for (int g = 0; g < ngroups; ++g) {
+        const bool px = g + 1 < ngroups;
+        const int gn = g;
+        const long xo = px ? patch_offset(g + 1) : 0;
+        const int nb = (g + 1) & 1;
+        const int xb = H2_XBASE + (g & 1) * H2_XB;
+        half8 as[2], am[2], bsa[4], bsb[4];
+        const int aS = 4 * H2_TAPU + (SPLIT ? (2 * kh + ks) : (kh + 2 * ks)) * 64 + 32 * it + c;     // [a0 | a1]
+        const int aM = 4 * H2_TAPU + rowA * 64 + 32 * it + c;                                       // a0 for both halves
+        const int bS = xb + (rowA + (1 - ks) * (SPLIT ? 1 : 2)) * H2_PL + (4 * jq) * HP_RS + c + SH4;   // [b1 | b0]
+
+        // ======== first stage: taps (0,1) (2,3) [4] from weight buffer A
+        LA(a0x, aP); LB(b1, xb + bP1 + B1OFF, 0); LB(b0a, xb + bP1, 0);
+        pair(a0x, 1, g, gn, xo, nb, px, 0, xb + bP1,
+             [&] { LA(a0y, 2 * H2_TAPU + aP); LB(b1, xb + 2 + bP32 + B1OFF, 0); },
+             [&] { LB(b0a, xb + 2 + bP32, 0); });
+        pair(a0y, 0, g, gn, xo, nb, px, 2 * H2_TAPU, xb + 2 + bP32,
+             [&] { LA(as, aS); LB(bsa, bS, 0); },
+             [&] { LB(bsb, bS, 1); });
+        LA(am, aM);
+        NBE_SB; MM8(acc1, as, bsa, 0, 0, 0, g, gn, xo, nb, px); NBE_SB;        // a0.b1 + a1.b0
+        MM8(acc1, as, bsb, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
+        {
+            const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            am[0] = ks ? am[0] : zero;                                       // [0 | a0]
+            am[1] = ks ? am[1] : zero;
+        }
+        NBE_SB; MM8(acc0, am, bsa, 0, 0, 0, g, gn, xo, nb, px); NBE_SB;        // a0.b0
+        MM8(acc0, am, bsb, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
+        __syncthreads();                                         // weight buffer B has landed
+
+        // ======== second stage: taps (5,6) (7,8) from weight buffer B
+        LA(a0x, H2_OFF_B + aP); LB(b1, xb + SH5 + bP32 + B1OFF, 0); LB(b0a, xb + SH5 + bP32, 0);
+        pair(a0x, 2, g, gn, xo, nb, px, H2_OFF_B, xb + SH5 + bP32,
+             [&] { LA(a0y, H2_OFF_B + 2 * H2_TAPU + aP); LB(b1, xb + SH7 + bP1 + B1OFF, 0); },
+             [&] { LB(b0a, xb + SH7 + bP1, 0); });
+        pair(a0y, 0, g, gn, xo, nb, px, H2_OFF_B + 2 * H2_TAPU, xb + SH7 + bP1, [] {}, [] {});
+        __syncthreads();                                         // weight buffer A and the patch of g+1 have landed
+    }
+#undef NBE_SB
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
+
+    // ---- epilogue: tile t = 8*mt + nt covers couts 32*it + 16*mt + 4*q .. +3 of position (4*jq + (nt >> 1),
+    // 16*(nt & 1) + c).  All global loads first (see conv_h3q_kernel).
+    {
+        const bool act = a.flags & F_ACT, res = a.flags & F_RES;
+        int unit[2];
+        bool uok[2];
+        f32x4 bv[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            unit[mt] = ct * 8 + 4 * it + 2 * mt + ks;
+            uok[mt] = unit[mt] < a.cout_groups;
+            if (!uok[mt]) unit[mt] = a.cout_groups - 1;
+            bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
+        }
+        long o[8];
+        bool ook[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const int yy = y0 + 4 * jq + (nt >> 1), xx = x0 + 16 * (nt & 1) + c;
+            ook[nt] = yy < a.Hv && xx < a.Wv;
+            o[nt] = ook[nt] ? ((long)z * a.Ho + yy) * a.Wo + xx : (long)z * a.Ho * a.Wo;
+        }
+        constexpr int PARTS = SPLIT ? 2 : 1;
+        half4 r0[16], r1[16];                                    // SPLIT: residual hi, lo;  !SPLIT: residual, its tangent
+        if (res) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const long rb = ((long)(PARTS * unit[t >> 3]) * a.res_pstride + o[t & 7]) * 16 + 8 * kh;
+                r0[t] = *(const half4*)((const char*)a.r + rb);
+                r1[t] = SPLIT ? *(const half4*)((const char*)a.r + rb + a.res_pstride * 16)
+                              : *(const half4*)((const char*)a.dr + rb);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int mt = t >> 3, nt = t & 7;
+            f32x4 v, dv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc0[t][e] + (SPLIT ? acc1[t][e] * H3_INV : 0.f) + bv[mt][e];
+                dv[e] = SPLIT ? 0.f : acc1[t][e];
+            }
+            if (res) {
+                if (SPLIT) v += join4(r0[t], r1[t]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += (float)r0[t][e]; dv[e] += (float)r1[t][e]; }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!SPLIT) dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                    v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                }
+            }
+            if (uok[mt] && ook[nt]) {
+                const long ob = ((long)(a.out_g0 + PARTS * unit[mt]) * a.out_pstride + o[nt]) * 16 + 8 * kh;
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *(half4*)((char*)a.y + ob) = hi;
+                if (SPLIT) *(half4*)((char*)a.y + ob + a.out_pstride * 16) = lo;
+                else {
+                    split4(dv, hi, lo);
+                    *(half4*)((char*)a.dy + ob) = hi;
+                }
+            }
+        }
+    }
+}
+
+template <bool SPLIT>
+static void launch_h2q(ConvKArgs ka, int ctiles, hipStream_t s) {
+    constexpr size_t smem = (size_t)H2_LDS_UNITS * 16;
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
+    auto kern = conv_h2q_kernel<SPLIT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    ka.tny = (ka.Hv + H2_ROWS - 1) / H2_ROWS;
+    ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
+    ka.ntiles = ka.Dv * ka.tny * ka.tnx;
+    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
+}
+
 template <int MODE, bool VEL, bool HAS_DX, int XDEPTH, bool SPLIT>
 static void launch_h3_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
     typedef H3Geom<MODE, SPLIT> G;
@@ -1047,6 +1333,8 @@ void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_d
     static const bool shape32 = getenv("NBE_H3_SHAPE") && atoi(getenv("NBE_H3_SHAPE")) == 32;   // A/B: 32x32x16 MFMAs
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
         if (split && vel && has_dx && !shape32 && sched == 0) { launch_h3q(ka, ct, s); return; }
+        if (split && !vel && !shape32) { launch_h2q<true>(ka, ct, s); return; }
+        if (!split && vel && has_dx && !shape32) { launch_h2q<false>(ka, ct, s); return; }
         if (!split) { NBE_VD(launch_h3p_v, 0, false) }
         else if (sched == 1) { NBE_VD(launch_h3p_v, 1, true) }
         else { NBE_VD(launch_h3p_v, 0, true) }
