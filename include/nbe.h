@@ -119,6 +119,10 @@ int nbe_set_max_tile(nbe_ctx* ctx, int max_tile);
  * the time of the call, longest along the last axis on ties (512^3 / ndiv 4 on a 288 GB MI355X: four tiles of
  * 256 x 256 x 512).  Falls back to the caller's grid when merging is not exact or no weights are loaded. */
 int nbe_plan_tiles_ctx(nbe_ctx* ctx, const int64_t region[3], const int ndiv[3], int out_ndiv[3]);
+/* Schedule of the two full-resolution levels of the U-Net inside a tile: whole tensors, or slabs of `slab` output
+ * planes along z (even; the slab-sized tensors let a tile be as deep as the box: 512^3 runs as ONE tile).  Results are
+ * identical.  -1 (default, or env NBE_SLAB): chosen with the tiling by the memory that is free; 0: never; S: always. */
+int nbe_set_slab(nbe_ctx* ctx, int slab);
 
 /* growth_factor / vel_norm (cosmology.py:34-40, :130-141) in double precision on the host. */
 double nbe_growth_factor(double z, double Om);

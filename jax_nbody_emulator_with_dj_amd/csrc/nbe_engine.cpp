@@ -93,6 +93,8 @@ struct nbe_ctx {
     char* ws = nullptr;
     int64_t ws_bytes = 0;
     bool dry = false;
+    int slab = 0;                                 // z-slab schedule: planes per slab of the full-resolution levels (0 = whole tensors)
+    int slab_forced = -1;                         // -1: chosen by memory; 0: never; S > 0: always S (nbe_set_slab, env NBE_SLAB)
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     // device-resident boxes of process_box
@@ -176,6 +178,16 @@ static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
     return t;
 }
 static void tfree(nbe_ctx* c, Tensor& t) { if (t.off >= 0) c->arena.release(t.off); t.off = -1; }
+// planes [z0, z0 + nz) of every channel plane of t as a tensor of its own (not owning: pstride, H, W unchanged)
+static Tensor zview(const Tensor& t, int z0, int nz) {
+    Tensor v = t;
+    v.off = -1;
+    const int64_t sh = (int64_t)z0 * t.p.H * t.p.W * 4;          // floats: one voxel of a plane is 16 bytes
+    if (v.p.x) v.p.x += sh;
+    if (v.p.dx) v.p.dx += sh;
+    v.p.D = nz;
+    return v;
+}
 
 static int prof_entry(nbe_ctx* c, const std::string& name) {
     for (size_t i = 0; i < c->prof_entries.size(); ++i) if (c->prof_entries[i].name == name) return (int)i;
@@ -367,12 +379,106 @@ static int network(nbe_ctx* c, const Tensor& tin, Tensor* yout) {
     return 0;
 }
 
-// bytes of workspace a (D,H,W) input needs: a dry run of the network through the arena (no launches); < 0 on error
+// Where the head writes: the (C, OD, OH, OW) output boxes and the anchor of this tile in them.
+struct HeadOut { void* disp; void* velo; int out_dtype; int OD, OH, OW, a0, a1, a2; float Dz, vel_fac; };
+
+static void run_head(nbe_ctx* c, const Tensor& y, const Tensor& xin, const HeadOut& h, int zoff) {
+    if (c->dry) return;
+    launch_head(y.p, xin.p, 48, c->out_chan, h.Dz, h.vel_fac, c->vel, h.disp, h.velo, h.out_dtype, h.OD, h.OH, h.OW,
+                h.a0 + zoff, h.a1, h.a2, c->prec, c->stream);
+}
+
+// The same network with the two full-resolution levels run in slabs of S output planes (S even): the encoder blocks
+// conv_l00 / conv_l01 (+ the crop of the skip connection and down_l0) and the decoder blocks up_r0 / conv_r00 /
+// conv_r01 (+ head) only ever hold slab-sized tensors, so a tile can be as deep as the box (no halo recompute along
+// z inside it) at a fraction of the workspace.  Neighbouring slabs recompute the 2-plane overlaps of the 3x3x3
+// layers: (S + 6) / S on the first hidden tensor, less further down.  Everything is the whole-tensor schedule on
+// z-views of the same tensors; results are identical.
+static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S) {
+    const int m = c->mid;
+    const int D = tin.p.D, H = tin.p.H, W = tin.p.W;
+    const int Y = D - 8;                                          // planes of the level-0 encoder output
+    Tensor skip0 = talloc(c, m, Y - 80, H - 88, W - 88);         // its centre crop by 40: the level-0 skip connection
+    Tensor t = talloc(c, m, Y / 2, (H - 8) / 2, (W - 8) / 2);    // down_l0 output
+    if (skip0.off < 0 || t.off < 0) return fail("workspace exhausted (level 0)");
+    const Layer* Ld = find_layer(c, "down_l0", "conv_0");
+    if (!Ld) return fail("missing layer down_l0/conv_0");
+    for (int z = 0; z < Y; z += S) {
+        const int n = std::min(S, Y - z);
+        Tensor a, y0;
+        if (resblock(c, "conv_l00", zview(tin, z, n + 8), false, true, m, m, &a)) return 1;
+        if (resblock(c, "conv_l01", a, true, true, m, m, &y0)) return 1;
+        tfree(c, a);
+        const int i0 = std::max(0, 40 - z), i1 = std::min(n, Y - 40 - z);      // planes of this slab inside the crop
+        if (i1 > i0 && !c->dry) {
+            Planes sp = y0.p; sp.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
+            launch_crop(sp, 40, zview(skip0, z + i0 - 40, i1 - i0).p, 0, c->vel, c->stream, i0);
+        }
+        {
+            const Tensor tv = zview(t, z / 2, n / 2);
+            ConvLaunch cl; cl.in = y0.p; cl.Dv = tv.p.D; cl.Hv = tv.p.H; cl.Wv = tv.p.W; cl.out = tv.p; cl.flags = F_ACT;
+            run_conv(c, *Ld, cl, true);
+        }
+        tfree(c, y0);
+    }
+
+    Tensor y1, y2, cat1, cat2, r;
+    if (resblock(c, "conv_l1", t, true, true, m, m, &y1)) return 1;
+    tfree(c, t);
+    cat1 = talloc(c, 2 * m, y1.p.D - 32, y1.p.H - 32, y1.p.W - 32);
+    if (cat1.off < 0) return fail("workspace exhausted (cat1)");
+    crop_into(c, y1, 16, cat1);
+    if (downblock(c, "down_l1", y1, &t)) return 1;
+    tfree(c, y1);
+    if (resblock(c, "conv_l2", t, true, true, m, m, &y2)) return 1;
+    tfree(c, t);
+    cat2 = talloc(c, 2 * m, y2.p.D - 8, y2.p.H - 8, y2.p.W - 8);
+    if (cat2.off < 0) return fail("workspace exhausted (cat2)");
+    crop_into(c, y2, 4, cat2);
+    if (downblock(c, "down_l2", y2, &t)) return 1;
+    tfree(c, y2);
+    if (resblock(c, "conv_c", t, true, true, m, m, &r)) return 1;
+    tfree(c, t);
+    if (upblock(c, "up_r2", r, cat2)) return 1;
+    tfree(c, r);
+    if (resblock(c, "conv_r2", cat2, true, true, m, 2 * m, &r)) return 1;
+    tfree(c, cat2);
+    if (upblock(c, "up_r1", r, cat1)) return 1;
+    tfree(c, r);
+    if (resblock(c, "conv_r1", cat1, true, true, m, 2 * m, &r)) return 1;      // r: level-1 decoder output
+    tfree(c, cat1);
+    if (2 * r.p.D != skip0.p.D || 2 * r.p.H != skip0.p.H || 2 * r.p.W != skip0.p.W)
+        return fail("internal: level-0 concat geometry mismatch");
+
+    const int Yo = skip0.p.D - 8;                                 // output planes (= D - 96)
+    for (int z = 0; z < Yo; z += S) {
+        const int n = std::min(S, Yo - z);
+        Tensor cat = talloc(c, 2 * m, n + 8, skip0.p.H, skip0.p.W), q, y;
+        if (cat.off < 0) return fail("workspace exhausted (cat0 slab)");
+        if (!c->dry) {
+            Planes sp = zview(skip0, z, n + 8).p;
+            launch_crop(sp, 0, cat.p, 0, c->vel, c->stream, 0);
+        }
+        if (upblock(c, "up_r0", zview(r, z / 2, (n + 8) / 2), cat)) return 1;
+        if (resblock(c, "conv_r00", cat, true, true, m, 2 * m, &q)) return 1;
+        tfree(c, cat);
+        if (resblock(c, "conv_r01", q, true, false, c->out_chan, m, &y)) return 1;
+        tfree(c, q);
+        run_head(c, y, zview(tin, z, n + 96), ho, z);
+        tfree(c, y);
+    }
+    tfree(c, r); tfree(c, skip0);
+    return 0;
+}
+
+// bytes of workspace a (D,H,W) input needs with the current schedule (c->slab): a dry run of the network through
+// the arena (no launches); < 0 on error
 static int64_t workspace_need(nbe_ctx* c, int D, int H, int W) {
     c->dry = true;
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
-    const int rc = network(c, tin, &y);
+    HeadOut ho{};
+    const int rc = c->slab > 0 ? network_stream(c, tin, ho, c->slab) : network(c, tin, &y);
     c->dry = false;
     return rc ? -1 : c->arena.high;
 }
@@ -405,8 +511,10 @@ static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int 
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
     // core :132-134: x = x * (Dz / 6)
     launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f, c->prec, c->stream);
+    const HeadOut ho{disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, Dz, vel_fac};
+    if (c->slab > 0) return network_stream(c, tin, ho, c->slab);
     if (network(c, tin, &y)) return 1;
-    launch_head(y.p, tin.p, 48, c->out_chan, Dz, vel_fac, c->vel, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, c->prec, c->stream);
+    run_head(c, y, tin, ho, 0);
     return 0;
 }
 
@@ -539,6 +647,7 @@ int nbe_create(int device_id, nbe_ctx** out) {
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     if (const char* e = getenv("NBE_MAX_TILE")) c->max_tile = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("NBE_SLAB")) c->slab_forced = atoi(e) >= 0 ? (atoi(e) & ~1) : -1;
     *out = c;
     return 0;
 }
@@ -628,6 +737,7 @@ int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float 
     const int OD = D - 96, OH = H - 96, OW = W - 96;
     const int64_t in_bytes = (int64_t)c->in_chan * D * H * W * 4, out_bytes = (int64_t)c->out_chan * OD * OH * OW * 4;
     const bool xin_dev = is_device_ptr(x), out_dev = is_device_ptr(disp);
+    c->slab = 0;                                              // single inputs run on whole tensors
     if (ensure_workspace(c, D, H, W)) return 1;
     const float* xd = (const float*)x;
     if (!xin_dev) {
@@ -675,27 +785,63 @@ int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int
     return 0;
 }
 
+// Schedule for a (D,H,W) input under a memory budget: 0 = whole tensors, S > 0 = z-slab schedule with S planes per
+// slab (the deepest that fits), -1 = nothing fits.  *need receives the workspace bytes of the choice.
+static int choose_slab(nbe_ctx* c, int D, int H, int W, int64_t budget, int64_t* need_out) {
+    const int forced = c->slab_forced;
+    const int keep = c->slab;
+    int result = -1;
+    // deeper slabs than 128 planes buy < 1 % (the 2-plane overlaps are already < 5 % there) for tens of GB of workspace
+    const int cand[4] = {0, 128, 64, 32};
+    for (int i = 0; i < 4 && result < 0; ++i) {
+        int S = cand[i];
+        if (forced == 0 && S != 0) break;
+        if (forced > 0) { if (i > 0) break; S = forced & ~1; }
+        if (S > 0 && D - 8 <= S) continue;                        // a single slab is the whole-tensor schedule
+        c->slab = S;
+        const int64_t need = workspace_need(c, D, H, W);
+        if (need >= 0 && need <= budget) { result = S; if (need_out) *need_out = need; }
+    }
+    c->slab = keep;
+    return result;
+}
+
 // The grid process_region will run: among all merges of the caller's sub-boxes (exact only when crop % 8 == 0 on
 // every axis) with tile edge <= max_tile, the one with the largest tile volume whose workspace fits the device
 // memory that is free now (plus what this context already holds, minus `reserve`); ties go to the tile that is
 // longest along the last (fastest) axis.  512^3 / ndiv 4 on a 288 GB MI355X: four tiles of 256 x 256 x 512
 // (input 352 x 352 x 608, a ~175 GB workspace), 12 % fewer FLOPs than eight tiles of 256^3.
+static int64_t plan_budget(nbe_ctx* c, int64_t reserve) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    // NBE_MEM_FRACTION (default 1): share of the free memory this context may plan with -- for rigs that run several
+    // ranks on one card, where every rank sees the same free memory at the same time
+    static const double frac = getenv("NBE_MEM_FRACTION") ? std::min(1.0, std::max(0.01, atof(getenv("NBE_MEM_FRACTION")))) : 1.0;
+    return (int64_t)(((double)free_b + (double)c->ws_bytes) * frac) - reserve - ((int64_t)3 << 30);
+}
+
 static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int64_t reserve, int out_ndiv[3]) {
     for (int a = 0; a < 3; ++a) out_ndiv[a] = ndiv[a];
-    if (c->max_tile <= 0 || !c->have_weights) return 0;
+    c->slab = 0;
+    if (!c->have_weights) return 0;
+    const int64_t budget = plan_budget(c, reserve);
+    if (budget < 0) return 0;
+    {   // schedule for the caller's own grid (the fallback of everything below)
+        const int64_t d = region[0] / ndiv[0] + 96, h = region[1] / ndiv[1] + 96, w = region[2] / ndiv[2] + 96;
+        if (d >= 104 && h >= 104 && w >= 104 && d % 8 == 0 && h % 8 == 0 && w % 8 == 0) {
+            const int sl = choose_slab(c, (int)d, (int)h, (int)w, budget, nullptr);
+            c->slab = sl > 0 ? sl : 0;
+        }
+    }
+    if (c->max_tile <= 0) return 0;
     int64_t crop[3];
     for (int a = 0; a < 3; ++a) {
         if (ndiv[a] < 1 || region[a] < 1) return fail("sizes and ndiv must be positive");
         crop[a] = region[a] / ndiv[a];
         if (crop[a] % 8 != 0 || crop[a] * ndiv[a] != region[a]) return 0;      // merging would not be exact
     }
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    // NBE_MEM_FRACTION (default 1): share of the free memory this context may plan with -- for rigs that run several
-    // ranks on one card, where every rank sees the same free memory at the same time
-    static const double frac = getenv("NBE_MEM_FRACTION") ? std::min(1.0, std::max(0.01, atof(getenv("NBE_MEM_FRACTION")))) : 1.0;
-    const int64_t budget = (int64_t)(((double)free_b + (double)c->ws_bytes) * frac) - reserve - ((int64_t)3 << 30);
     int64_t best_vol = 0, best_w = 0;
+    int best_slab = c->slab;
     for (int m0 = 1; m0 <= ndiv[0]; ++m0) {
         if (ndiv[0] % m0 || crop[0] * m0 > c->max_tile) continue;
         for (int m1 = 1; m1 <= ndiv[1]; ++m1) {
@@ -706,13 +852,14 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
                 const int64_t w = e2 * 1000000 + e1 * 1000 + e0;               // tie-break: long last axis
                 if (vol < best_vol || (vol == best_vol && w <= best_w)) continue;
                 if (check_dims((int)e0 + 96, (int)e1 + 96, (int)e2 + 96)) { (void)nbe_last_error(); continue; }
-                const int64_t need = workspace_need(c, (int)e0 + 96, (int)e1 + 96, (int)e2 + 96);
-                if (need < 0 || need > budget) continue;
-                best_vol = vol; best_w = w;
+                const int sl = choose_slab(c, (int)e0 + 96, (int)e1 + 96, (int)e2 + 96, budget, nullptr);
+                if (sl < 0) continue;
+                best_vol = vol; best_w = w; best_slab = sl;
                 out_ndiv[0] = ndiv[0] / m0; out_ndiv[1] = ndiv[1] / m1; out_ndiv[2] = ndiv[2] / m2;
             }
         }
     }
+    c->slab = best_slab;
     return 0;
 }
 
@@ -728,6 +875,13 @@ int nbe_set_precision(nbe_ctx* c, int prec) {
     if (c->have_weights && prec != c->prec)
         return fail("nbe_set_precision must be called before the weights are loaded (they are packed per precision)");
     c->prec = prec;
+    return 0;
+}
+
+int nbe_set_slab(nbe_ctx* c, int slab) {
+    if (!c) return fail("null context");
+    if (slab > 0 && (slab & 1)) return fail("slab must be even");
+    c->slab_forced = slab < 0 ? -1 : slab;
     return 0;
 }
 
@@ -755,22 +909,37 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     // Internal tiling: with an explicit sub-box list the caller's grid is used as given; otherwise adjacent
     // sub-boxes may be merged into larger tiles (nbe_plan_tiles) -- identical results, less halo recompute.
     int ndiv_eff[3] = {ndiv_in[0], ndiv_in[1], ndiv_in[2]};
-    if (!order && c->max_tile > 0) {
+    {
         HIPCHK(hipSetDevice(c->device));
         // host arrays in / out are staged in device buffers that are allocated below: keep room for them
         const int64_t in_b = (int64_t)S0 * S1 * S2 * c->in_chan * 4;
         const int64_t out_b = (int64_t)O0 * O1 * O2 * c->out_chan * (out_dtype == NBE_F16 ? 2 : 4) * (c->vel ? 2 : 1);
         const int64_t reserve = (is_device_ptr(box) ? 0 : std::max<int64_t>(0, in_b - c->box_in_bytes)) +
                                 (is_device_ptr(disp) ? 0 : std::max<int64_t>(0, out_b - c->box_out_bytes));
-        if (plan_tiles_mem(c, region, ndiv_in, reserve, ndiv_eff)) return 1;
+        auto tile_dims = [&](int* d, int* h, int* w) {
+            *d = (int)(region[0] / ndiv_eff[0]) + 96; *h = (int)(region[1] / ndiv_eff[1]) + 96; *w = (int)(region[2] / ndiv_eff[2]) + 96;
+        };
+        // schedule (whole tensors or z-slabs) of a given grid under the memory that is free now
+        auto schedule_for_grid = [&]() {
+            c->slab = 0;
+            int d, h, w; tile_dims(&d, &h, &w);
+            const int64_t budget = plan_budget(c, reserve);
+            if (budget >= 0 && c->have_weights && d >= 104 && h >= 104 && w >= 104 && !(d % 8) && !(h % 8) && !(w % 8)) {
+                const int sl = choose_slab(c, d, h, w, budget, nullptr);
+                if (sl > 0) c->slab = sl;
+            }
+        };
+        if (order) schedule_for_grid();                          // explicit sub-box list: the caller's grid as given
+        else if (plan_tiles_mem(c, region, ndiv_in, reserve, ndiv_eff)) return 1;
         // fall back to cubic tiles <= 256, then to the caller's grid, when the workspace cannot be allocated after all
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 2 && !order; ++attempt) {
             if (ndiv_eff[0] == ndiv_in[0] && ndiv_eff[1] == ndiv_in[1] && ndiv_eff[2] == ndiv_in[2]) break;
-            const int d = (int)(region[0] / ndiv_eff[0]) + 96, h = (int)(region[1] / ndiv_eff[1]) + 96, w = (int)(region[2] / ndiv_eff[2]) + 96;
+            int d, h, w; tile_dims(&d, &h, &w);
             if (!ensure_workspace(c, d, h, w)) break;
             (void)hipGetLastError();
             if (attempt == 0 && c->max_tile > 256) { if (nbe_plan_tiles(region, ndiv_in, 256, ndiv_eff)) return 1; }
             else { ndiv_eff[0] = ndiv_in[0]; ndiv_eff[1] = ndiv_in[1]; ndiv_eff[2] = ndiv_in[2]; }
+            schedule_for_grid();
         }
     }
     const int* ndiv = ndiv_eff;

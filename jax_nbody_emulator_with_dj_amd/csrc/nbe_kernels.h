@@ -88,7 +88,8 @@ void launch_gather(const float* box, int C, int Db, int Hb, int Wb, int a0, int 
 void launch_to_planes(const float* src, int C, const Planes& dst, bool tangent, float scale, int prec, hipStream_t s);
 void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, int prec, hipStream_t s);
 // centre crop by c voxels per side into planes [g0, g0+src.G) of dst
-void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s);
+// (cz >= 0: crop along z by cz instead of c -- the z-slab schedule copies plane ranges)
+void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s, int cz = -1);
 // head: disp = (y + x0)*6 ; vel = dy*(vf*6) + x0*(vf*6/Dz); x0 = input planes cropped by `c0`;
 // written to a (C, Db, Hb, Wb) box at origin (a0,a1,a2); out_dtype 0 = f32, 1 = f16
 void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,

@@ -419,24 +419,24 @@ void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, int 
 __global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ sx, const float* __restrict__ sdx,
                                                    long spstride, int SH, int SW, int c, float* __restrict__ dx_,
                                                    float* __restrict__ ddx, long dpstride, int g0, int G, int D,
-                                                   int H, int W) {
+                                                   int H, int W, int cz) {
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long V = (long)D * H * W;
     if (v >= V) return;
     const int g = blockIdx.y;
     const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
     const int y = rem / W, x = rem - y * W;
-    const long sv = ((long)(z + c) * SH + (y + c)) * SW + (x + c);
+    const long sv = ((long)(z + cz) * SH + (y + c)) * SW + (x + c);
     const long so = ((long)g * spstride + sv) * 4, dof = ((long)(g0 + g) * dpstride + v) * 4;
     *(f32x4*)(dx_ + dof) = *(const f32x4*)(sx + so);
     if (sdx) *(f32x4*)(ddx + dof) = *(const f32x4*)(sdx + so);
 }
 
-void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s) {
+void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s, int cz) {
     const long V = dst.vox();
     hipLaunchKernelGGL(crop_kernel, dim3((unsigned)((V + 255) / 256), src.G), dim3(256), 0, s, src.x,
                        vel ? src.dx : nullptr, src.pstride, src.H, src.W, c, dst.x, dst.dx, dst.pstride, g0,
-                       src.G, dst.D, dst.H, dst.W);
+                       src.G, dst.D, dst.H, dst.W, cz < 0 ? c : cz);
 }
 
 template <typename OT>

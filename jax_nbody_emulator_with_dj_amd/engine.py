@@ -147,6 +147,10 @@ class Engine:
         check(self._l.nbe_set_max_tile(self._h, int(max_tile)))
         self.max_tile = int(max_tile)
 
+    def set_slab(self, slab):
+        """-1: the engine chooses whole tensors or z-slabs by memory; 0: whole tensors; S (even): slabs of S planes."""
+        check(self._l.nbe_set_slab(self._h, int(slab)))
+
     def plan_tiles(self, region, ndiv):
         """The sub-box grid the engine will actually run for `region` cut by `ndiv` (nbe_plan_tiles_ctx): the
         largest exact merge whose workspace fits the free device memory."""

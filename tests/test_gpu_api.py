@@ -219,6 +219,26 @@ def test_internal_tile_merging_is_exact():
     _close(v1, v0, 1e-6, 1e-5, "merged tiles vel")
 
 
+def test_z_slab_schedule_is_identical():
+    """The z-slab schedule (nbe_set_slab) runs the same kernels on z-views of slab-sized tensors: bit-identical fields."""
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
+    p = _synthetic(17, 8)
+    size, ndiv = (160, 32, 48), (1, 2, 1)                       # tile input 256 x 112 x 144: 248 level-0 planes
+    box = np.random.default_rng(4).standard_normal((3,) + size).astype(np.float32)
+    proc = J.SubboxProcessor(m, p, J.SubboxConfig(size=size, ndiv=ndiv))
+    eng = get_engine(m, 0)
+    try:
+        eng.set_slab(0)
+        d0, v0 = proc.process_box(box, Z, OM, show_progress=False)
+        for S in (32, 64, 100):
+            eng.set_slab(S)
+            d1, v1 = proc.process_box(box, Z, OM, show_progress=False)
+            assert np.array_equal(d1, d0) and np.array_equal(v1, v0), S
+    finally:
+        eng.set_slab(-1)
+
+
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():
     """BASELINE config 3: 512^3 box, ndiv=(4,4,4), compute_vel=True, production width, resident tensors.
     Size-independent property: the engine's default execution (merged tiles: four of 352 x 352 x 608 input when
