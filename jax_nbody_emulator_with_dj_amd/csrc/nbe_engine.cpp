@@ -927,6 +927,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
             if (budget >= 0 && c->have_weights && d >= 104 && h >= 104 && w >= 104 && !(d % 8) && !(h % 8) && !(w % 8)) {
                 const int sl = choose_slab(c, d, h, w, budget, nullptr);
                 if (sl > 0) c->slab = sl;
+                else if (sl < 0 && c->slab_forced < 0 && d - 8 > 32) c->slab = 32;   // nothing fits the budget: smallest footprint
             }
         };
         if (order) schedule_for_grid();                          // explicit sub-box list: the caller's grid as given
