@@ -142,7 +142,7 @@ def main():
         else:
             sb = sharding.ShardedBox(eng, size, ndiv, rank, world, comm_stream=torch.cuda.Stream(device=dev))
             step = lambda: sb.process(data, Dz, vf, disp, velo)
-            plan = "%s tiles per rank brick" % (eng.plan_tiles(sb.bshape, sb.nd_local),)
+            plan = "%s tiles per rank brick" % (eng.plan_tiles(sb.bshape, sb.nd_local, periodic_box=False),)
         for _ in range(warmup):
             step()
         fence()

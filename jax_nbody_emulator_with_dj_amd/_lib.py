@@ -54,9 +54,10 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "nbe_plan_tiles": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
-    "nbe_plan_tiles_ctx": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nbe_plan_tiles_ctx": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "nbe_set_max_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_set_slab": (C.c_int, [C.c_void_p, C.c_int]),
+    "nbe_set_periodic": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_growth_factor": (C.c_double, [C.c_double, C.c_double]),
     "nbe_vel_norm": (C.c_double, [C.c_double, C.c_double]),

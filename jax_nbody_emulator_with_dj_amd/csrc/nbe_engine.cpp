@@ -95,6 +95,8 @@ struct nbe_ctx {
     bool dry = false;
     int slab = 0;                                 // z-slab schedule: planes per slab of the full-resolution levels (0 = whole tensors)
     int slab_forced = -1;                         // -1: chosen by memory; 0: never; S > 0: always S (nbe_set_slab, env NBE_SLAB)
+    bool pyx = false;                             // current tile runs in periodic-yx mode (it spans the periodic box in y and x)
+    bool pyx_allowed = true;                      // env NBE_PERIODIC=0 turns the mode off
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     // device-resident boxes of process_box
@@ -171,11 +173,29 @@ static Planes ws_planes(nbe_ctx* c, int G, int D, int H, int W, int64_t* off_out
     return p;
 }
 
-struct Tensor { Planes p; int64_t off = -1; };
+// pad > 0: the tensor carries a periodic halo of `pad` voxels in y and x around its interior (periodic-yx mode)
+struct Tensor { Planes p; int64_t off = -1; int pad = 0; };
 static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
     Tensor t;
     t.p = ws_planes(c, planes_for(C, c->prec), D, H, W, &t.off);
     return t;
+}
+// interior Hi x Wi plus a y/x halo of `pad`
+static Tensor tallocp(nbe_ctx* c, int C, int D, int Hi, int Wi, int pad) {
+    Tensor t = talloc(c, C, D, Hi + 2 * pad, Wi + 2 * pad);
+    t.pad = pad;
+    return t;
+}
+// the interior as output planes: same strides, origin moved by (pad, pad)
+static Planes inner(const Tensor& t) {
+    Planes p = t.p;
+    const int64_t sh = (int64_t)t.pad * (t.p.W + 1) * 4;
+    if (p.x) p.x += sh;
+    if (p.dx) p.dx += sh;
+    return p;
+}
+static void fill_halo(nbe_ctx* c, const Tensor& t) {
+    if (t.pad > 0 && !c->dry) launch_fill_yx(t.p, t.pad, c->vel, c->stream);
 }
 static void tfree(nbe_ctx* c, Tensor& t) { if (t.off >= 0) c->arena.release(t.off); t.off = -1; }
 // planes [z0, z0 + nz) of every channel plane of t as a tensor of its own (not owning: pstride, H, W unchanged)
@@ -256,31 +276,37 @@ static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer)
 // schedule
 // ------------------------------------------------------------------------------------------------
 
-// StyleResNetBlock3DVel (style_blocks_vel.py:96-166): skip 1x1x1 cropped by 2, conv-act-conv, add, [act]
+// StyleResNetBlock3DVel (style_blocks_vel.py:96-166): skip 1x1x1 cropped by 2, conv-act-conv, add, [act].
+// Periodic-yx mode (x.pad = 1): y and x do not shrink -- every 3x3x3 convolution reads its input's wrap-around halo
+// and writes the interior of a tensor of the same padded size, whose halo is filled afterwards; z shrinks as always.
 static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, bool final_act,
                     int cout, int cmid, Tensor* out) {
     const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
     if (!Ls || !L0 || !L1) return fail("missing layers of block %s", name);
-    const int D = x.p.D, H = x.p.H, W = x.p.W;
+    const int D = x.p.D, H = x.p.H, W = x.p.W, pad = x.pad;
+    const int Hi = H - 2 * pad, Wi = W - 2 * pad;                 // interior of x (pad = 0: all of it)
+    const int sy = pad ? 0 : 2;                                  // what one 3x3x3 convolution takes off y and x
     // The second convolution adds the skip as a residual and writes its result over it (every lane reads its residual
     // elements before it stores the same elements): one full-resolution tensor pair less at the workspace peak.
-    Tensor s = talloc(c, cout, D - 4, H - 4, W - 4);
-    Tensor h = talloc(c, cmid, D - 2, H - 2, W - 2);
+    Tensor s = tallocp(c, cout, D - 4, Hi - 2 * sy, Wi - 2 * sy, pad);
+    Tensor h = tallocp(c, cmid, D - 2, Hi - sy, Wi - sy, pad);
     if (s.off < 0 || h.off < 0) return fail("workspace exhausted in block %s", name);
     {
-        ConvLaunch cl; cl.in = x.p; cl.in_off = (2L * H + 2) * W + 2;
-        cl.Dv = D - 4; cl.Hv = H - 4; cl.Wv = W - 4; cl.out = s.p; cl.flags = 0;
+        ConvLaunch cl; cl.in = x.p; cl.in_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
+        cl.Dv = D - 4; cl.Hv = Hi - 2 * sy; cl.Wv = Wi - 2 * sy; cl.out = inner(s); cl.flags = 0;
         run_conv(c, *Ls, cl, has_dx);
     }
     {
-        ConvLaunch cl; cl.in = x.p; cl.Dv = D - 2; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = h.p; cl.flags = F_ACT;
+        ConvLaunch cl; cl.in = x.p; cl.Dv = D - 2; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = inner(h); cl.flags = F_ACT;
         run_conv(c, *L0, cl, has_dx);
     }
+    fill_halo(c, h);
     {
-        ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = H - 4; cl.Wv = W - 4; cl.out = s.p;
-        cl.res = s.p; cl.flags = F_RES | (final_act ? F_ACT : 0);
+        ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = h.p.H - 2; cl.Wv = h.p.W - 2; cl.out = inner(s);
+        cl.res = inner(s); cl.flags = F_RES | (final_act ? F_ACT : 0);
         run_conv(c, *L1, cl, true);
     }
+    fill_halo(c, s);
     tfree(c, h);
     *out = s;
     return 0;
@@ -298,13 +324,16 @@ static int downblock(nbe_ctx* c, const char* name, const Tensor& x, Tensor* out)
 }
 
 // up-sample into planes [mid/4, 2*mid/4) of the concat tensor (core :166-169: concat([skip, up]))
-static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& cat) {
+// (xcrop: centre crop of x in y and x before up-sampling; the result goes to the interior of cat)
+static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& cat, int xcrop = 0) {
     const Layer* L = find_layer(c, name, "conv_0");
     if (!L) return fail("missing layer %s/conv_0", name);
-    if (cat.p.D != 2 * x.p.D || cat.p.H != 2 * x.p.H || cat.p.W != 2 * x.p.W)
+    const int Hx = x.p.H - 2 * xcrop, Wx = x.p.W - 2 * xcrop;
+    if (cat.p.D != 2 * x.p.D || cat.p.H - 2 * cat.pad != 2 * Hx || cat.p.W - 2 * cat.pad != 2 * Wx)
         return fail("internal: concat geometry mismatch in %s", name);
     for (int p = 0; p < 8; ++p) {
-        ConvLaunch cl; cl.in = x.p; cl.Dv = x.p.D; cl.Hv = x.p.H; cl.Wv = x.p.W; cl.out = cat.p;
+        ConvLaunch cl; cl.in = x.p; cl.in_off = ((int64_t)xcrop * x.p.W + xcrop);
+        cl.Dv = x.p.D; cl.Hv = Hx; cl.Wv = Wx; cl.out = inner(cat);
         cl.out_g0 = c->mid / (c->prec == PREC_F16 ? 8 : 4); cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
         cl.flags = F_ACT; cl.set = p;
         run_conv(c, *L, cl, true);
@@ -385,7 +414,7 @@ struct HeadOut { void* disp; void* velo; int out_dtype; int OD, OH, OW, a0, a1, 
 static void run_head(nbe_ctx* c, const Tensor& y, const Tensor& xin, const HeadOut& h, int zoff) {
     if (c->dry) return;
     launch_head(y.p, xin.p, 48, c->out_chan, h.Dz, h.vel_fac, c->vel, h.disp, h.velo, h.out_dtype, h.OD, h.OH, h.OW,
-                h.a0 + zoff, h.a1, h.a2, c->prec, c->stream);
+                h.a0 + zoff, h.a1, h.a2, c->prec, c->stream, y.pad);
 }
 
 // The same network with the two full-resolution levels run in slabs of S output planes (S even): the encoder blocks
@@ -394,13 +423,23 @@ static void run_head(nbe_ctx* c, const Tensor& y, const Tensor& xin, const HeadO
 // z inside it) at a fraction of the workspace.  Neighbouring slabs recompute the 2-plane overlaps of the 3x3x3
 // layers: (S + 6) / S on the first hidden tensor, less further down.  Everything is the whole-tensor schedule on
 // z-views of the same tensors; results are identical.
+//
+// Periodic-yx mode (tin.pad = 1: the tile spans the whole periodic box in y and x).  The two full-resolution levels
+// do not pad-and-shrink in y and x: their tensors are N + 2 wide, every 3x3x3 convolution reads the wrap-around halo
+// of its input and the halo of its output is filled afterwards -- the same arithmetic per voxel as the reference's
+// 48-voxel periodic padding, without computing the halo voxels (about 10 % of the FLOPs of a 512^3 box).  The levels
+// below keep the padded scheme: down_l0 runs on the interior and its output is extended periodically by the 22
+// voxels of context those levels consume; up_r0 takes the centre of the level-1 result.
 static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S) {
-    const int m = c->mid;
+    const int m = c->mid, pad = tin.pad;
     const int D = tin.p.D, H = tin.p.H, W = tin.p.W;
+    const int Hi = H - 2 * pad, Wi = W - 2 * pad;
     const int Y = D - 8;                                          // planes of the level-0 encoder output
-    Tensor skip0 = talloc(c, m, Y - 80, H - 88, W - 88);         // its centre crop by 40: the level-0 skip connection
-    Tensor t = talloc(c, m, Y / 2, (H - 8) / 2, (W - 8) / 2);    // down_l0 output
-    if (skip0.off < 0 || t.off < 0) return fail("workspace exhausted (level 0)");
+    // the level-0 skip connection: centre crop by 40 (z only in periodic-yx mode)
+    Tensor skip0 = pad ? tallocp(c, m, Y - 80, Hi, Wi, pad) : talloc(c, m, Y - 80, H - 88, W - 88);
+    // down_l0 output; periodic-yx: on the interior first (td), then extended by 22 voxels of periodic context (t)
+    Tensor td = pad ? talloc(c, m, Y / 2, Hi / 2, Wi / 2) : talloc(c, m, Y / 2, (H - 8) / 2, (W - 8) / 2);
+    if (skip0.off < 0 || td.off < 0) return fail("workspace exhausted (level 0)");
     const Layer* Ld = find_layer(c, "down_l0", "conv_0");
     if (!Ld) return fail("missing layer down_l0/conv_0");
     for (int z = 0; z < Y; z += S) {
@@ -412,14 +451,21 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
         const int i0 = std::max(0, 40 - z), i1 = std::min(n, Y - 40 - z);      // planes of this slab inside the crop
         if (i1 > i0 && !c->dry) {
             Planes sp = y0.p; sp.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
-            launch_crop(sp, 40, zview(skip0, z + i0 - 40, i1 - i0).p, 0, c->vel, c->stream, i0);
+            launch_crop(sp, pad ? 0 : 40, zview(skip0, z + i0 - 40, i1 - i0).p, 0, c->vel, c->stream, i0);
         }
         {
-            const Tensor tv = zview(t, z / 2, n / 2);
-            ConvLaunch cl; cl.in = y0.p; cl.Dv = tv.p.D; cl.Hv = tv.p.H; cl.Wv = tv.p.W; cl.out = tv.p; cl.flags = F_ACT;
+            const Tensor tv = zview(td, z / 2, n / 2);
+            ConvLaunch cl; cl.in = inner(y0); cl.Dv = tv.p.D; cl.Hv = tv.p.H; cl.Wv = tv.p.W; cl.out = tv.p; cl.flags = F_ACT;
             run_conv(c, *Ld, cl, true);
         }
         tfree(c, y0);
+    }
+    Tensor t = td;
+    if (pad) {
+        t = talloc(c, m, td.p.D, td.p.H + 44, td.p.W + 44);
+        if (t.off < 0) return fail("workspace exhausted (level 1 input)");
+        if (!c->dry) launch_wrap_pad(td.p, t.p, 22, c->vel, c->stream);
+        tfree(c, td);
     }
 
     Tensor y1, y2, cat1, cat2, r;
@@ -447,19 +493,22 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     tfree(c, r);
     if (resblock(c, "conv_r1", cat1, true, true, m, 2 * m, &r)) return 1;      // r: level-1 decoder output
     tfree(c, cat1);
-    if (2 * r.p.D != skip0.p.D || 2 * r.p.H != skip0.p.H || 2 * r.p.W != skip0.p.W)
+    // periodic-yx: the level-1 result carries 2 voxels of y/x context that the full-resolution decoder does not need
+    const int rcrop = pad ? 2 : 0;
+    if (2 * r.p.D != skip0.p.D || 2 * (r.p.H - 2 * rcrop) != skip0.p.H - 2 * pad || 2 * (r.p.W - 2 * rcrop) != skip0.p.W - 2 * pad)
         return fail("internal: level-0 concat geometry mismatch");
 
     const int Yo = skip0.p.D - 8;                                 // output planes (= D - 96)
     for (int z = 0; z < Yo; z += S) {
         const int n = std::min(S, Yo - z);
-        Tensor cat = talloc(c, 2 * m, n + 8, skip0.p.H, skip0.p.W), q, y;
+        Tensor cat = tallocp(c, 2 * m, n + 8, skip0.p.H - 2 * pad, skip0.p.W - 2 * pad, pad), q, y;
         if (cat.off < 0) return fail("workspace exhausted (cat0 slab)");
         if (!c->dry) {
             Planes sp = zview(skip0, z, n + 8).p;
             launch_crop(sp, 0, cat.p, 0, c->vel, c->stream, 0);
         }
-        if (upblock(c, "up_r0", zview(r, z / 2, (n + 8) / 2), cat)) return 1;
+        if (upblock(c, "up_r0", zview(r, z / 2, (n + 8) / 2), cat, rcrop)) return 1;
+        fill_halo(c, cat);
         if (resblock(c, "conv_r00", cat, true, true, m, 2 * m, &q)) return 1;
         tfree(c, cat);
         if (resblock(c, "conv_r01", q, true, false, c->out_chan, m, &y)) return 1;
@@ -471,12 +520,23 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     return 0;
 }
 
+// periodic-yx tiles: z as usual; y and x are the box itself (+ 2 halo voxels), a multiple of 8 with room for the
+// 22 voxels of periodic context of the level-1 input
+static int check_dims_pyx(int D, int H, int W) {
+    if (D < 104 || D % 8 != 0) return fail("input depth %d unsupported: must be >= 104 and a multiple of 8", D);
+    const int v[2] = {H - 2, W - 2};
+    for (int i = 0; i < 2; ++i)
+        if (v[i] < 48 || v[i] % 8 != 0) return fail("periodic extent %d unsupported: must be >= 48 and a multiple of 8", v[i]);
+    return 0;
+}
+
 // bytes of workspace a (D,H,W) input needs with the current schedule (c->slab): a dry run of the network through
 // the arena (no launches); < 0 on error
 static int64_t workspace_need(nbe_ctx* c, int D, int H, int W) {
     c->dry = true;
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
+    tin.pad = c->pyx ? 1 : 0;
     HeadOut ho{};
     const int rc = c->slab > 0 ? network_stream(c, tin, ho, c->slab) : network(c, tin, &y);
     c->dry = false;
@@ -509,6 +569,7 @@ static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int 
                       int OD, int OH, int OW, int a0, int a1, int a2) {
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
+    tin.pad = c->pyx ? 1 : 0;                                   // periodic-yx: (H, W) = box extent + 2, gathered from origin - 1
     // core :132-134: x = x * (Dz / 6)
     launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f, c->prec, c->stream);
     const HeadOut ho{disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, Dz, vel_fac};
@@ -648,6 +709,7 @@ int nbe_create(int device_id, nbe_ctx** out) {
     c->stream = c->own_stream;
     if (const char* e = getenv("NBE_MAX_TILE")) c->max_tile = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("NBE_SLAB")) c->slab_forced = atoi(e) >= 0 ? (atoi(e) & ~1) : -1;
+    if (const char* e = getenv("NBE_PERIODIC")) c->pyx_allowed = atoi(e) != 0;
     *out = c;
     return 0;
 }
@@ -737,7 +799,7 @@ int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float 
     const int OD = D - 96, OH = H - 96, OW = W - 96;
     const int64_t in_bytes = (int64_t)c->in_chan * D * H * W * 4, out_bytes = (int64_t)c->out_chan * OD * OH * OW * 4;
     const bool xin_dev = is_device_ptr(x), out_dev = is_device_ptr(disp);
-    c->slab = 0;                                              // single inputs run on whole tensors
+    c->slab = 0; c->pyx = false;                              // single inputs run on whole tensors, no periodicity
     if (ensure_workspace(c, D, H, W)) return 1;
     const float* xd = (const float*)x;
     if (!xin_dev) {
@@ -787,22 +849,26 @@ int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int
 
 // Schedule for a (D,H,W) input under a memory budget: 0 = whole tensors, S > 0 = z-slab schedule with S planes per
 // slab (the deepest that fits), -1 = nothing fits.  *need receives the workspace bytes of the choice.
-static int choose_slab(nbe_ctx* c, int D, int H, int W, int64_t budget, int64_t* need_out) {
+static int choose_slab(nbe_ctx* c, int D, int H, int W, int64_t budget, int64_t* need_out, bool pyx = false) {
     const int forced = c->slab_forced;
     const int keep = c->slab;
+    const bool keep_p = c->pyx;
     int result = -1;
+    c->pyx = pyx;
     // deeper slabs than 128 planes buy < 1 % (the 2-plane overlaps are already < 5 % there) for tens of GB of workspace
     const int cand[4] = {0, 128, 64, 32};
     for (int i = 0; i < 4 && result < 0; ++i) {
         int S = cand[i];
+        if (pyx && S == 0) { if (forced == 0) break; continue; }  // periodic-yx exists only in the slab schedule
         if (forced == 0 && S != 0) break;
-        if (forced > 0) { if (i > 0) break; S = forced & ~1; }
-        if (S > 0 && D - 8 <= S) continue;                        // a single slab is the whole-tensor schedule
+        if (forced > 0) { if (i > (pyx ? 1 : 0)) break; S = forced & ~1; }
+        if (!pyx && S > 0 && D - 8 <= S) continue;                // a single slab is the whole-tensor schedule
         c->slab = S;
         const int64_t need = workspace_need(c, D, H, W);
         if (need >= 0 && need <= budget) { result = S; if (need_out) *need_out = need; }
     }
     c->slab = keep;
+    c->pyx = keep_p;
     return result;
 }
 
@@ -820,19 +886,33 @@ static int64_t plan_budget(nbe_ctx* c, int64_t reserve) {
     return (int64_t)(((double)free_b + (double)c->ws_bytes) * frac) - reserve - ((int64_t)3 << 30);
 }
 
-static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int64_t reserve, int out_ndiv[3]) {
+static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int64_t reserve, bool full_yx,
+                          int out_ndiv[3]) {
     for (int a = 0; a < 3; ++a) out_ndiv[a] = ndiv[a];
     c->slab = 0;
+    c->pyx = false;
     if (!c->have_weights) return 0;
+    full_yx = full_yx && c->pyx_allowed;
     const int64_t budget = plan_budget(c, reserve);
     if (budget < 0) return 0;
-    {   // schedule for the caller's own grid (the fallback of everything below)
-        const int64_t d = region[0] / ndiv[0] + 96, h = region[1] / ndiv[1] + 96, w = region[2] / ndiv[2] + 96;
-        if (d >= 104 && h >= 104 && w >= 104 && d % 8 == 0 && h % 8 == 0 && w % 8 == 0) {
-            const int sl = choose_slab(c, (int)d, (int)h, (int)w, budget, nullptr);
-            c->slab = sl > 0 ? sl : 0;
+    // schedule of a tile of e0 x e1 x e2 output voxels: periodic-yx when it spans the box in y and x, else padded
+    auto schedule = [&](int64_t e0, int64_t e1, int64_t e2, bool spans, int* slab, bool* pyx) -> bool {
+        if (spans && full_yx && !check_dims_pyx((int)e0 + 96, (int)e1 + 2, (int)e2 + 2)) {
+            const int sl = choose_slab(c, (int)e0 + 96, (int)e1 + 2, (int)e2 + 2, budget, nullptr, true);
+            if (sl > 0) { *slab = sl; *pyx = true; return true; }
         }
-    }
+        if (check_dims((int)e0 + 96, (int)e1 + 96, (int)e2 + 96)) return false;
+        const int sl = choose_slab(c, (int)e0 + 96, (int)e1 + 96, (int)e2 + 96, budget, nullptr, false);
+        if (sl < 0) return false;
+        *slab = sl; *pyx = false;
+        return true;
+    };
+    int best_slab = 0;
+    bool best_pyx = false;
+    schedule(region[0] / ndiv[0], region[1] / ndiv[1], region[2] / ndiv[2], ndiv[1] == 1 && ndiv[2] == 1 &&
+             region[1] % ndiv[1] == 0 && region[2] % ndiv[2] == 0, &best_slab, &best_pyx);       // the caller's own grid
+    (void)nbe_last_error();
+    c->slab = best_slab; c->pyx = best_pyx;
     if (c->max_tile <= 0) return 0;
     int64_t crop[3];
     for (int a = 0; a < 3; ++a) {
@@ -841,7 +921,6 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
         if (crop[a] % 8 != 0 || crop[a] * ndiv[a] != region[a]) return 0;      // merging would not be exact
     }
     int64_t best_vol = 0, best_w = 0;
-    int best_slab = c->slab;
     for (int m0 = 1; m0 <= ndiv[0]; ++m0) {
         if (ndiv[0] % m0 || crop[0] * m0 > c->max_tile) continue;
         for (int m1 = 1; m1 <= ndiv[1]; ++m1) {
@@ -851,22 +930,21 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
                 const int64_t e0 = crop[0] * m0, e1 = crop[1] * m1, e2 = crop[2] * m2, vol = e0 * e1 * e2;
                 const int64_t w = e2 * 1000000 + e1 * 1000 + e0;               // tie-break: long last axis
                 if (vol < best_vol || (vol == best_vol && w <= best_w)) continue;
-                if (check_dims((int)e0 + 96, (int)e1 + 96, (int)e2 + 96)) { (void)nbe_last_error(); continue; }
-                const int sl = choose_slab(c, (int)e0 + 96, (int)e1 + 96, (int)e2 + 96, budget, nullptr);
-                if (sl < 0) continue;
-                best_vol = vol; best_w = w; best_slab = sl;
+                int sl = 0; bool px = false;
+                if (!schedule(e0, e1, e2, m1 == ndiv[1] && m2 == ndiv[2], &sl, &px)) { (void)nbe_last_error(); continue; }
+                best_vol = vol; best_w = w; best_slab = sl; best_pyx = px;
                 out_ndiv[0] = ndiv[0] / m0; out_ndiv[1] = ndiv[1] / m1; out_ndiv[2] = ndiv[2] / m2;
             }
         }
     }
-    c->slab = best_slab;
+    c->slab = best_slab; c->pyx = best_pyx;
     return 0;
 }
 
-int nbe_plan_tiles_ctx(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int out_ndiv[3]) {
+int nbe_plan_tiles_ctx(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int periodic_box, int out_ndiv[3]) {
     if (!c || !region || !ndiv || !out_ndiv) return fail("null argument");
     HIPCHK(hipSetDevice(c->device));
-    return plan_tiles_mem(c, region, ndiv, 0, out_ndiv);
+    return plan_tiles_mem(c, region, ndiv, 0, periodic_box != 0, out_ndiv);
 }
 
 int nbe_set_precision(nbe_ctx* c, int prec) {
@@ -875,6 +953,12 @@ int nbe_set_precision(nbe_ctx* c, int prec) {
     if (c->have_weights && prec != c->prec)
         return fail("nbe_set_precision must be called before the weights are loaded (they are packed per precision)");
     c->prec = prec;
+    return 0;
+}
+
+int nbe_set_periodic(nbe_ctx* c, int on) {
+    if (!c) return fail("null context");
+    c->pyx_allowed = on != 0;
     return 0;
 }
 
@@ -916,22 +1000,32 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         const int64_t out_b = (int64_t)O0 * O1 * O2 * c->out_chan * (out_dtype == NBE_F16 ? 2 : 4) * (c->vel ? 2 : 1);
         const int64_t reserve = (is_device_ptr(box) ? 0 : std::max<int64_t>(0, in_b - c->box_in_bytes)) +
                                 (is_device_ptr(disp) ? 0 : std::max<int64_t>(0, out_b - c->box_out_bytes));
-        auto tile_dims = [&](int* d, int* h, int* w) {
-            *d = (int)(region[0] / ndiv_eff[0]) + 96; *h = (int)(region[1] / ndiv_eff[1]) + 96; *w = (int)(region[2] / ndiv_eff[2]) + 96;
+        // the region is the periodic box itself in y and x: tiles that span it may run in periodic-yx mode
+        const bool full_yx = c->pyx_allowed && origin[1] == 0 && origin[2] == 0 && region[1] == bsize[1] && region[2] == bsize[2];
+        auto tile_dims = [&](int* d, int* h, int* w) {            // input dims of a tile of the current grid / mode
+            const int ext = c->pyx ? 2 : 96;
+            *d = (int)(region[0] / ndiv_eff[0]) + 96; *h = (int)(region[1] / ndiv_eff[1]) + ext; *w = (int)(region[2] / ndiv_eff[2]) + ext;
         };
-        // schedule (whole tensors or z-slabs) of a given grid under the memory that is free now
+        // schedule (whole tensors or z-slabs, padded or periodic-yx) of a given grid under the memory that is free now
         auto schedule_for_grid = [&]() {
-            c->slab = 0;
-            int d, h, w; tile_dims(&d, &h, &w);
+            c->slab = 0; c->pyx = false;
             const int64_t budget = plan_budget(c, reserve);
-            if (budget >= 0 && c->have_weights && d >= 104 && h >= 104 && w >= 104 && !(d % 8) && !(h % 8) && !(w % 8)) {
+            if (budget < 0 || !c->have_weights) return;
+            const int e0 = (int)(region[0] / ndiv_eff[0]), e1 = (int)(region[1] / ndiv_eff[1]), e2 = (int)(region[2] / ndiv_eff[2]);
+            if (full_yx && ndiv_eff[1] == 1 && ndiv_eff[2] == 1 && !check_dims_pyx(e0 + 96, e1 + 2, e2 + 2)) {
+                const int sl = choose_slab(c, e0 + 96, e1 + 2, e2 + 2, budget, nullptr, true);
+                if (sl > 0) { c->slab = sl; c->pyx = true; return; }
+            }
+            (void)nbe_last_error();
+            const int d = e0 + 96, h = e1 + 96, w = e2 + 96;
+            if (d >= 104 && h >= 104 && w >= 104 && !(d % 8) && !(h % 8) && !(w % 8)) {
                 const int sl = choose_slab(c, d, h, w, budget, nullptr);
                 if (sl > 0) c->slab = sl;
                 else if (sl < 0 && c->slab_forced < 0 && d - 8 > 32) c->slab = 32;   // nothing fits the budget: smallest footprint
             }
         };
         if (order) schedule_for_grid();                          // explicit sub-box list: the caller's grid as given
-        else if (plan_tiles_mem(c, region, ndiv_in, reserve, ndiv_eff)) return 1;
+        else if (plan_tiles_mem(c, region, ndiv_in, reserve, full_yx, ndiv_eff)) return 1;
         // fall back to cubic tiles <= 256, then to the caller's grid, when the workspace cannot be allocated after all
         for (int attempt = 0; attempt < 2 && !order; ++attempt) {
             if (ndiv_eff[0] == ndiv_in[0] && ndiv_eff[1] == ndiv_in[1] && ndiv_eff[2] == ndiv_in[2]) break;
@@ -945,8 +1039,9 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     }
     const int* ndiv = ndiv_eff;
     const int c0 = (int)(region[0] / ndiv[0]), c1 = (int)(region[1] / ndiv[1]), c2 = (int)(region[2] / ndiv[2]);   // subbox.py:49 (floor)
-    const int D = c0 + 96, H = c1 + 96, W = c2 + 96;
-    if (check_dims(D, H, W)) return 1;
+    const int hal = c->pyx ? 1 : 48;                              // y/x context gathered with the tile
+    const int D = c0 + 96, H = c1 + 2 * hal, W = c2 + 2 * hal;
+    if (c->pyx ? check_dims_pyx(D, H, W) : check_dims(D, H, W)) return 1;
     for (int i = 0; i < 3; ++i)
         if (oorigin[i] < 0 || oorigin[i] + region[i] > osize[i]) return fail("output region does not fit the output array");
     HIPCHK(hipSetDevice(c->device));
@@ -981,7 +1076,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         if (idx < 0 || idx >= total) return fail("sub-box index %d out of range (0..%d)", idx, total - 1);
         // subbox.py:60-66: row-major over ndiv, last axis fastest
         const int a0 = (idx / (ndiv[1] * ndiv[2])) * c0, a1 = ((idx / ndiv[2]) % ndiv[1]) * c1, a2 = (idx % ndiv[2]) * c2;
-        if (run_subbox(c, bd, S0, S1, S2, (int)origin[0] + a0 - 48, (int)origin[1] + a1 - 48, (int)origin[2] + a2 - 48,
+        if (run_subbox(c, bd, S0, S1, S2, (int)origin[0] + a0 - 48, (int)origin[1] + a1 - hal, (int)origin[2] + a2 - hal,
                        D, H, W, Dz, vel_fac, dd, vd, out_dtype, O0, O1, O2,
                        (int)oorigin[0] + a0, (int)oorigin[1] + a1, (int)oorigin[2] + a2)) return 1;
         if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb(k + 1, n, user); }

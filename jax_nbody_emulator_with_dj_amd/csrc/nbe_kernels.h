@@ -94,7 +94,11 @@ void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, 
 // written to a (C, Db, Hb, Wb) box at origin (a0,a1,a2); out_dtype 0 = f32, 1 = f16
 void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                 int prec, hipStream_t s);
+                 int prec, hipStream_t s, int pad = 0);
+
+// periodic y/x halo of width `pad` of a tensor whose interior has been written; dst = src extended periodically in y/x
+void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s);
+void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s);
 
 // NBE_DBG builds: per-phase cycle totals of the f16x3 3x3x3 kernel since the last call (zeros otherwise)
 void h3q_read_stamps(double* out16, hipStream_t s);

@@ -439,19 +439,72 @@ void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, 
                        src.G, dst.D, dst.H, dst.W, cz < 0 ? c : cz);
 }
 
+// Periodic y/x halo of a tensor whose interior [pad, H - pad) x [pad, W - pad) has been written: every halo voxel
+// takes the interior voxel one period away.  16-byte units, all channel planes, primal and tangent.
+__global__ __launch_bounds__(256) void fill_yx_kernel(float* __restrict__ x, float* __restrict__ dx, long pstride,
+                                                      int G, int D, int H, int W, int pad) {
+    const int Hi = H - 2 * pad, Wi = W - 2 * pad;
+    const long per = (long)H * W - (long)Hi * Wi;                 // halo voxels of one z plane
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * D) return;
+    const int z = (int)(idx / per);
+    long r = idx - (long)z * per;
+    int y, xx;
+    if (r < (long)pad * W) { y = (int)(r / W); xx = (int)(r - (long)y * W); }                           // top rows
+    else if (r < 2L * pad * W) { r -= (long)pad * W; y = H - pad + (int)(r / W); xx = (int)(r % W); }  // bottom rows
+    else { r -= 2L * pad * W; y = pad + (int)(r / (2 * pad)); const int k = (int)(r % (2 * pad)); xx = k < pad ? k : W - 2 * pad + k; }
+    const int ys = pad + ((y - pad) % Hi + Hi) % Hi, xs = pad + ((xx - pad) % Wi + Wi) % Wi;
+    const long d = ((long)z * H + y) * W + xx, sidx = ((long)z * H + ys) * W + xs;
+    const int g = blockIdx.y;
+    *(f32x4*)(x + ((long)g * pstride + d) * 4) = *(const f32x4*)(x + ((long)g * pstride + sidx) * 4);
+    if (dx) *(f32x4*)(dx + ((long)g * pstride + d) * 4) = *(const f32x4*)(dx + ((long)g * pstride + sidx) * 4);
+}
+
+void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s) {
+    const long per = (long)t.H * t.W - (long)(t.H - 2 * pad) * (t.W - 2 * pad);
+    const long n = per * t.D;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_yx_kernel, dim3((unsigned)((n + 255) / 256), t.G), dim3(256), 0, s, t.x, vel ? t.dx : nullptr,
+                       t.pstride, t.G, t.D, t.H, t.W, pad);
+}
+
+// dst (D, Hs + 2*pad, Ws + 2*pad) = src (D, Hs, Ws) extended periodically in y and x by `pad` voxels
+__global__ __launch_bounds__(256) void wrap_pad_kernel(const float* __restrict__ sx, const float* __restrict__ sdx,
+                                                       long spstride, int Hs, int Ws, float* __restrict__ dx_,
+                                                       float* __restrict__ ddx, long dpstride, int D, int H, int W,
+                                                       int pad) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= (long)D * H * W) return;
+    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const int ys = ((y - pad) % Hs + Hs) % Hs, xs = ((x - pad) % Ws + Ws) % Ws;
+    const long sv = ((long)z * Hs + ys) * Ws + xs;
+    const int g = blockIdx.y;
+    *(f32x4*)(dx_ + ((long)g * dpstride + v) * 4) = *(const f32x4*)(sx + ((long)g * spstride + sv) * 4);
+    if (sdx) *(f32x4*)(ddx + ((long)g * dpstride + v) * 4) = *(const f32x4*)(sdx + ((long)g * spstride + sv) * 4);
+}
+
+void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s) {
+    const long V = dst.vox();
+    hipLaunchKernelGGL(wrap_pad_kernel, dim3((unsigned)((V + 255) / 256), src.G), dim3(256), 0, s, src.x,
+                       vel ? src.dx : nullptr, src.pstride, src.H, src.W, dst.x, dst.dx, dst.pstride, dst.D, dst.H, dst.W, pad);
+}
+
 template <typename OT>
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                    long ypstride, int D, int H, int W,
                                                    const float* __restrict__ xin, long xpstride, int XH, int XW,
                                                    int c0, int C, float k_dy, float k_x0, OT* __restrict__ disp,
                                                    OT* __restrict__ velo, int Db, int Hb, int Wb, int a0, int a1,
-                                                   int a2) {
-    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long V = (long)D * H * W;
-    if (v >= V) return;
-    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
-    const int yy = rem / W, x = rem - yy * W;
-    const long xv = ((long)(z + c0) * XH + (yy + c0)) * XW + (x + c0);
+                                                   int a2, int pad) {
+    // pad > 0: y and xin carry a periodic y/x halo of `pad` voxels; the loop runs over the interior
+    const int Hi = H - 2 * pad, Wi = W - 2 * pad, c1 = pad > 0 ? pad : c0;
+    const long vi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= (long)D * Hi * Wi) return;
+    const int z = (int)(vi / ((long)Hi * Wi)), rem = (int)(vi - (long)z * Hi * Wi);
+    const int yy = rem / Wi, x = rem - yy * Wi;
+    const long v = ((long)z * H + yy + pad) * W + x + pad;
+    const long xv = ((long)(z + c0) * XH + (yy + c1)) * XW + (x + c1);
     const long bo = ((long)(a0 + z) * Hb + (a1 + yy)) * Wb + (a2 + x);
     const long bstride = (long)Db * Hb * Wb;
     for (int g = 0; 4 * g < C; ++g) {
@@ -472,19 +525,19 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, 
 
 void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                 int prec, hipStream_t s) {
-    if (prec_is_half(prec)) { launch_head_h8(y, xin, c0, C, Dz, vel_fac, vel, disp, velo, out_dtype, Db, Hb, Wb, a0, a1, a2, prec_parts(prec), s); return; }
-    const long V = y.vox();
+                 int prec, hipStream_t s, int pad) {
+    if (prec_is_half(prec)) { launch_head_h8(y, xin, c0, C, Dz, vel_fac, vel, disp, velo, out_dtype, Db, Hb, Wb, a0, a1, a2, prec_parts(prec), s, pad); return; }
+    const long V = (long)y.D * (y.H - 2 * pad) * (y.W - 2 * pad);
     const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
     dim3 grid((unsigned)((V + 255) / 256)), block(256);
     if (out_dtype == 0)
         hipLaunchKernelGGL(head_kernel<float>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D, y.H,
                            y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (float*)disp, (float*)velo,
-                           Db, Hb, Wb, a0, a1, a2);
+                           Db, Hb, Wb, a0, a1, a2, pad);
     else
         hipLaunchKernelGGL(head_kernel<_Float16>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D,
                            y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (_Float16*)disp,
-                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2);
+                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, pad);
 }
 
 }  // namespace nbe

@@ -1460,13 +1460,15 @@ __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ 
                                                       const float* __restrict__ xin, long xpstride, int XH, int XW,
                                                       int c0, int C, float k_dy, float k_x0, OT* __restrict__ disp,
                                                       OT* __restrict__ velo, int Db, int Hb, int Wb, int a0, int a1,
-                                                      int a2, int parts) {
-    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long V = (long)D * H * W;
-    if (v >= V) return;
-    const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
-    const int yy = rem / W, x = rem - yy * W;
-    const long xv = ((long)(z + c0) * XH + (yy + c0)) * XW + (x + c0);
+                                                      int a2, int parts, int pad) {
+    // pad > 0: y and xin carry a periodic y/x halo of `pad` voxels; the loop runs over the interior
+    const int Hi = H - 2 * pad, Wi = W - 2 * pad, c1 = pad > 0 ? pad : c0;
+    const long vi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vi >= (long)D * Hi * Wi) return;
+    const int z = (int)(vi / ((long)Hi * Wi)), rem = (int)(vi - (long)z * Hi * Wi);
+    const int yy = rem / Wi, x = rem - yy * Wi;
+    const long v = ((long)z * H + yy + pad) * W + x + pad;
+    const long xv = ((long)(z + c0) * XH + (yy + c1)) * XW + (x + c1);
     const long bo = ((long)(a0 + z) * Hb + (a1 + yy)) * Wb + (a2 + x);
     const long bstride = (long)Db * Hb * Wb;
     for (int g = 0; 8 * g < C; ++g) {
@@ -1489,18 +1491,18 @@ __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ 
 
 void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                     void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                    int parts, hipStream_t s) {
-    const long V = y.vox();
+                    int parts, hipStream_t s, int pad) {
+    const long V = (long)y.D * (y.H - 2 * pad) * (y.W - 2 * pad);
     const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
     dim3 grid((unsigned)((V + 255) / 256)), block(256);
     if (out_dtype == 0)
         hipLaunchKernelGGL(head_h8_kernel<float>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D, y.H,
                            y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (float*)disp, (float*)velo,
-                           Db, Hb, Wb, a0, a1, a2, parts);
+                           Db, Hb, Wb, a0, a1, a2, parts, pad);
     else
         hipLaunchKernelGGL(head_h8_kernel<_Float16>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D,
                            y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (_Float16*)disp,
-                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, parts);
+                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, parts, pad);
 }
 
 }  // namespace nbe

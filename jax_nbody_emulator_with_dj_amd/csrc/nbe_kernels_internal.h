@@ -45,6 +45,6 @@ void launch_gather_h8(const float* box, int C, int Db, int Hb, int Wb, int a0, i
 void launch_from_planes_h8(const float* src, const Planes& geom, int C, float* dst, int parts, hipStream_t s);
 void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
                     void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
-                    int parts, hipStream_t s);
+                    int parts, hipStream_t s, int pad = 0);
 
 }  // namespace nbe

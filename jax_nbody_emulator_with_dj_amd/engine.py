@@ -151,12 +151,17 @@ class Engine:
         """-1: the engine chooses whole tensors or z-slabs by memory; 0: whole tensors; S (even): slabs of S planes."""
         check(self._l.nbe_set_slab(self._h, int(slab)))
 
-    def plan_tiles(self, region, ndiv):
+    def set_periodic(self, on):
+        """Periodic-yx mode for tiles that span the periodic box in y and x (default on)."""
+        check(self._l.nbe_set_periodic(self._h, 1 if on else 0))
+
+    def plan_tiles(self, region, ndiv, periodic_box=True):
         """The sub-box grid the engine will actually run for `region` cut by `ndiv` (nbe_plan_tiles_ctx): the
-        largest exact merge whose workspace fits the free device memory."""
+        largest exact merge whose workspace fits the free device memory.  periodic_box: `region` is a whole periodic
+        box (process_box) rather than a brick of one (process_region)."""
         out = (C.c_int * 3)()
         check(self._l.nbe_plan_tiles_ctx(self._h, (C.c_int64 * 3)(*[int(r) for r in region]),
-                                         (C.c_int * 3)(*[int(n) for n in ndiv]), out))
+                                         (C.c_int * 3)(*[int(n) for n in ndiv]), 1 if periodic_box else 0, out))
         return tuple(out)
 
     def synchronize(self):

@@ -152,7 +152,7 @@ class ShardedBox:
         messages are in flight on the communication stream; boundary sub-boxes wait for them."""
         cur = torch.cuda.current_stream()
         # the engine merges sub-boxes into larger tiles when that is exact (nbe_plan_tiles); split on that grid
-        nd = self.eng.plan_tiles(self.bshape, self.nd_local)
+        nd = self.eng.plan_tiles(self.bshape, self.nd_local, periodic_box=False)
         interior, boundary = split_interior(nd, self.bshape)
         if self.comm_stream is not None and interior:
             self.comm_stream.wait_stream(cur)

@@ -239,6 +239,36 @@ def test_z_slab_schedule_is_identical():
         eng.set_slab(-1)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f32", "f16"])
+def test_periodic_yx_mode_is_identical(prec, monkeypatch):
+    """A tile that spans the periodic box in y and x takes its y/x context from 1-voxel wrap-around halos filled layer by
+    layer at the two full-resolution levels, instead of a 48-voxel padded input: same kernels, same arithmetic per
+    voxel -> the same fields as the padded schedule (nbe_set_periodic off), one slab or several."""
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    monkeypatch.setenv("NBE_PRECISION", prec)
+    m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
+    p = _synthetic(19, 8)
+    size, ndiv = (64, 48, 56), (2, 1, 1)
+    box = np.random.default_rng(6).standard_normal((3,) + size).astype(np.float32)
+    proc = J.SubboxProcessor(m, p, J.SubboxConfig(size=size, ndiv=ndiv))
+    eng = get_engine(m, 0)
+    try:
+        eng.set_periodic(False)
+        d0, v0 = proc.process_box(box, Z, OM, show_progress=False)
+        eng.set_periodic(True)
+        for S in (-1, 32):
+            eng.set_slab(S)
+            d1, v1 = proc.process_box(box, Z, OM, show_progress=False)
+            if prec == "f16":                                   # float32 sums may differ in the last bit before the f16 rounding
+                assert rel_l2(d1, d0) <= 1e-3 and rel_l2(v1, v0) <= 1e-2, S
+            else:
+                _close(d1, d0, 1e-6, 1e-5, "periodic-yx disp S=%d" % S)
+                _close(v1, v0, 1e-6, 1e-5, "periodic-yx vel S=%d" % S)
+    finally:
+        eng.set_periodic(True)
+        eng.set_slab(-1)
+
+
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():
     """BASELINE config 3: 512^3 box, ndiv=(4,4,4), compute_vel=True, production width, resident tensors.
     Size-independent property: the engine's default execution (merged tiles: four of 352 x 352 x 608 input when
