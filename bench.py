@@ -7,9 +7,9 @@ ndiv=(4,4,4), StyleNBodyEmulatorVelCore, float32, on N MI355X of one node.
          bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of process_box over the whole box (64 sub-boxes of 224^3 -> 128^3, which the engine
-merges into the largest tiles whose workspace fits the card -- ONE tile of 608^3 -> 512^3 on a free 288 GB
-MI355X, its two full-resolution levels run in z-slabs -- when that is exact; --max-tile 256 / 0 restrict it to 256^3
-tiles / disable it), with the input box and
+merges into the largest tiles whose workspace fits the card -- ONE tile on a free 288 GB MI355X, its two
+full-resolution levels run in z-slabs and, the tile being the periodic box itself, without halo recompute -- when that
+is exact; --max-tile 256 / 0 restrict it to 256^3 tiles / disable it), with the input box and
 the output boxes resident in HBM.  Arithmetic: float32-equivalent f16x3 split MFMA by default (`value`); the
 strict float32 MFMA path is timed on the same box and reported under "strict_f32".  Weights are synthetic (seeded; the pretrained blob is not
 available), which changes neither the FLOPs nor the bytes.  Rank 0 prints ONE JSON line.
@@ -184,7 +184,9 @@ def main():
         # see the file named beside each value) and are reported only when the configuration matches.
         traffic = None
         if (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
-            if plan.startswith("(1, 1, 1)"):
+            if plan.startswith("(1, 1, 1)") and os.environ.get("NBE_PERIODIC", "1") != "0":
+                traffic = 60.8e9            # profiles/r01_pmc_fetch_write_default_periodic.txt
+            elif plan.startswith("(1, 1, 1)"):
                 traffic = 69.5e9            # profiles/r01_pmc_fetch_write_default_onetile.txt
             elif plan.startswith("(2, 1, 1)"):
                 traffic = 89.0e9            # profiles/r01_pmc_fetch_write_default_tiles211.txt

@@ -97,6 +97,7 @@ struct nbe_ctx {
     int slab_forced = -1;                         // -1: chosen by memory; 0: never; S > 0: always S (nbe_set_slab, env NBE_SLAB)
     bool pyx = false;                             // current tile runs in periodic-yx mode (it spans the periodic box in y and x)
     bool pyx_allowed = true;                      // env NBE_PERIODIC=0 turns the mode off
+    bool pz = false;                              // ... and the tile also spans the box in z (only with pyx)
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     // device-resident boxes of process_box
@@ -435,15 +436,20 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     const int D = tin.p.D, H = tin.p.H, W = tin.p.W;
     const int Hi = H - 2 * pad, Wi = W - 2 * pad;
     const int Y = D - 8;                                          // planes of the level-0 encoder output
+    // Periodic in z too (the tile is the whole box): the 40 outermost planes of the level-0 encoder output on either
+    // side only feed the lower levels, whose input can be extended periodically in z just as in y and x.  The encoder
+    // then produces the Y - 80 planes of the skip connection only, and down_l0 the box's own (D - 96) / 2 planes.
+    const bool pz = pad && c->pz;
+    const int zlo = pz ? 40 : 0, zhi = pz ? Y - 40 : Y;
     // the level-0 skip connection: centre crop by 40 (z only in periodic-yx mode)
     Tensor skip0 = pad ? tallocp(c, m, Y - 80, Hi, Wi, pad) : talloc(c, m, Y - 80, H - 88, W - 88);
     // down_l0 output; periodic-yx: on the interior first (td), then extended by 22 voxels of periodic context (t)
-    Tensor td = pad ? talloc(c, m, Y / 2, Hi / 2, Wi / 2) : talloc(c, m, Y / 2, (H - 8) / 2, (W - 8) / 2);
+    Tensor td = pad ? talloc(c, m, pz ? (D - 96) / 2 : Y / 2, Hi / 2, Wi / 2) : talloc(c, m, Y / 2, (H - 8) / 2, (W - 8) / 2);
     if (skip0.off < 0 || td.off < 0) return fail("workspace exhausted (level 0)");
     const Layer* Ld = find_layer(c, "down_l0", "conv_0");
     if (!Ld) return fail("missing layer down_l0/conv_0");
-    for (int z = 0; z < Y; z += S) {
-        const int n = std::min(S, Y - z);
+    for (int z = zlo; z < zhi; z += S) {
+        const int n = std::min(S, zhi - z);
         Tensor a, y0;
         if (resblock(c, "conv_l00", zview(tin, z, n + 8), false, true, m, m, &a)) return 1;
         if (resblock(c, "conv_l01", a, true, true, m, m, &y0)) return 1;
@@ -454,17 +460,22 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
             launch_crop(sp, pad ? 0 : 40, zview(skip0, z + i0 - 40, i1 - i0).p, 0, c->vel, c->stream, i0);
         }
         {
-            const Tensor tv = zview(td, z / 2, n / 2);
-            ConvLaunch cl; cl.in = inner(y0); cl.Dv = tv.p.D; cl.Hv = tv.p.H; cl.Wv = tv.p.W; cl.out = tv.p; cl.flags = F_ACT;
-            run_conv(c, *Ld, cl, true);
+            // planes [d0, d1) of this slab go through down_l0 (periodic in z: only the box's own planes, 44 .. Y - 44)
+            const int d0 = pz ? std::max(z, 44) : z, d1 = pz ? std::min(z + n, Y - 44) : z + n;
+            if (d1 > d0) {
+                const Tensor tv = zview(td, (d0 - (pz ? 44 : 0)) / 2, (d1 - d0) / 2);
+                Tensor yv = zview(y0, d0 - z, d1 - d0);
+                ConvLaunch cl; cl.in = inner(yv); cl.Dv = tv.p.D; cl.Hv = tv.p.H; cl.Wv = tv.p.W; cl.out = tv.p; cl.flags = F_ACT;
+                run_conv(c, *Ld, cl, true);
+            }
         }
         tfree(c, y0);
     }
     Tensor t = td;
     if (pad) {
-        t = talloc(c, m, td.p.D, td.p.H + 44, td.p.W + 44);
+        t = talloc(c, m, td.p.D + (pz ? 44 : 0), td.p.H + 44, td.p.W + 44);
         if (t.off < 0) return fail("workspace exhausted (level 1 input)");
-        if (!c->dry) launch_wrap_pad(td.p, t.p, 22, c->vel, c->stream);
+        if (!c->dry) launch_wrap_pad(td.p, t.p, 22, c->vel, c->stream, pz ? 22 : 0);
         tfree(c, td);
     }
 
@@ -799,7 +810,7 @@ int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float 
     const int OD = D - 96, OH = H - 96, OW = W - 96;
     const int64_t in_bytes = (int64_t)c->in_chan * D * H * W * 4, out_bytes = (int64_t)c->out_chan * OD * OH * OW * 4;
     const bool xin_dev = is_device_ptr(x), out_dev = is_device_ptr(disp);
-    c->slab = 0; c->pyx = false;                              // single inputs run on whole tensors, no periodicity
+    c->slab = 0; c->pyx = false; c->pz = false;               // single inputs run on whole tensors, no periodicity
     if (ensure_workspace(c, D, H, W)) return 1;
     const float* xd = (const float*)x;
     if (!xin_dev) {
@@ -849,12 +860,13 @@ int nbe_plan_tiles(const int64_t region[3], const int ndiv[3], int max_tile, int
 
 // Schedule for a (D,H,W) input under a memory budget: 0 = whole tensors, S > 0 = z-slab schedule with S planes per
 // slab (the deepest that fits), -1 = nothing fits.  *need receives the workspace bytes of the choice.
-static int choose_slab(nbe_ctx* c, int D, int H, int W, int64_t budget, int64_t* need_out, bool pyx = false) {
+static int choose_slab(nbe_ctx* c, int D, int H, int W, int64_t budget, int64_t* need_out, bool pyx = false,
+                       bool pz = false) {
     const int forced = c->slab_forced;
     const int keep = c->slab;
-    const bool keep_p = c->pyx;
+    const bool keep_p = c->pyx, keep_z = c->pz;
     int result = -1;
-    c->pyx = pyx;
+    c->pyx = pyx; c->pz = pyx && pz;
     // deeper slabs than 128 planes buy < 1 % (the 2-plane overlaps are already < 5 % there) for tens of GB of workspace
     const int cand[4] = {0, 128, 64, 32};
     for (int i = 0; i < 4 && result < 0; ++i) {
@@ -868,7 +880,7 @@ static int choose_slab(nbe_ctx* c, int D, int H, int W, int64_t budget, int64_t*
         if (need >= 0 && need <= budget) { result = S; if (need_out) *need_out = need; }
     }
     c->slab = keep;
-    c->pyx = keep_p;
+    c->pyx = keep_p; c->pz = keep_z;
     return result;
 }
 
@@ -887,10 +899,10 @@ static int64_t plan_budget(nbe_ctx* c, int64_t reserve) {
 }
 
 static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int64_t reserve, bool full_yx,
-                          int out_ndiv[3]) {
+                          bool full_z, int out_ndiv[3]) {
     for (int a = 0; a < 3; ++a) out_ndiv[a] = ndiv[a];
     c->slab = 0;
-    c->pyx = false;
+    c->pyx = false; c->pz = false;
     if (!c->have_weights) return 0;
     full_yx = full_yx && c->pyx_allowed;
     const int64_t budget = plan_budget(c, reserve);
@@ -898,7 +910,7 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
     // schedule of a tile of e0 x e1 x e2 output voxels: periodic-yx when it spans the box in y and x, else padded
     auto schedule = [&](int64_t e0, int64_t e1, int64_t e2, bool spans, int* slab, bool* pyx) -> bool {
         if (spans && full_yx && !check_dims_pyx((int)e0 + 96, (int)e1 + 2, (int)e2 + 2)) {
-            const int sl = choose_slab(c, (int)e0 + 96, (int)e1 + 2, (int)e2 + 2, budget, nullptr, true);
+            const int sl = choose_slab(c, (int)e0 + 96, (int)e1 + 2, (int)e2 + 2, budget, nullptr, true, full_z && e0 == region[0]);
             if (sl > 0) { *slab = sl; *pyx = true; return true; }
         }
         if (check_dims((int)e0 + 96, (int)e1 + 96, (int)e2 + 96)) return false;
@@ -913,6 +925,7 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
              region[1] % ndiv[1] == 0 && region[2] % ndiv[2] == 0, &best_slab, &best_pyx);       // the caller's own grid
     (void)nbe_last_error();
     c->slab = best_slab; c->pyx = best_pyx;
+    c->pz = best_pyx && full_z && ndiv[0] == 1;
     if (c->max_tile <= 0) return 0;
     int64_t crop[3];
     for (int a = 0; a < 3; ++a) {
@@ -938,13 +951,14 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
         }
     }
     c->slab = best_slab; c->pyx = best_pyx;
+    c->pz = best_pyx && full_z && out_ndiv[0] == 1;
     return 0;
 }
 
 int nbe_plan_tiles_ctx(nbe_ctx* c, const int64_t region[3], const int ndiv[3], int periodic_box, int out_ndiv[3]) {
     if (!c || !region || !ndiv || !out_ndiv) return fail("null argument");
     HIPCHK(hipSetDevice(c->device));
-    return plan_tiles_mem(c, region, ndiv, 0, periodic_box != 0, out_ndiv);
+    return plan_tiles_mem(c, region, ndiv, 0, periodic_box != 0, periodic_box != 0, out_ndiv);
 }
 
 int nbe_set_precision(nbe_ctx* c, int prec) {
@@ -1002,19 +1016,21 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
                                 (is_device_ptr(disp) ? 0 : std::max<int64_t>(0, out_b - c->box_out_bytes));
         // the region is the periodic box itself in y and x: tiles that span it may run in periodic-yx mode
         const bool full_yx = c->pyx_allowed && origin[1] == 0 && origin[2] == 0 && region[1] == bsize[1] && region[2] == bsize[2];
+        const bool full_z = origin[0] == 0 && region[0] == bsize[0];        // ... and in z
         auto tile_dims = [&](int* d, int* h, int* w) {            // input dims of a tile of the current grid / mode
             const int ext = c->pyx ? 2 : 96;
             *d = (int)(region[0] / ndiv_eff[0]) + 96; *h = (int)(region[1] / ndiv_eff[1]) + ext; *w = (int)(region[2] / ndiv_eff[2]) + ext;
         };
         // schedule (whole tensors or z-slabs, padded or periodic-yx) of a given grid under the memory that is free now
         auto schedule_for_grid = [&]() {
-            c->slab = 0; c->pyx = false;
+            c->slab = 0; c->pyx = false; c->pz = false;
             const int64_t budget = plan_budget(c, reserve);
             if (budget < 0 || !c->have_weights) return;
             const int e0 = (int)(region[0] / ndiv_eff[0]), e1 = (int)(region[1] / ndiv_eff[1]), e2 = (int)(region[2] / ndiv_eff[2]);
             if (full_yx && ndiv_eff[1] == 1 && ndiv_eff[2] == 1 && !check_dims_pyx(e0 + 96, e1 + 2, e2 + 2)) {
-                const int sl = choose_slab(c, e0 + 96, e1 + 2, e2 + 2, budget, nullptr, true);
-                if (sl > 0) { c->slab = sl; c->pyx = true; return; }
+                const bool z1 = full_z && ndiv_eff[0] == 1;
+                const int sl = choose_slab(c, e0 + 96, e1 + 2, e2 + 2, budget, nullptr, true, z1);
+                if (sl > 0) { c->slab = sl; c->pyx = true; c->pz = z1; return; }
             }
             (void)nbe_last_error();
             const int d = e0 + 96, h = e1 + 96, w = e2 + 96;
@@ -1025,7 +1041,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
             }
         };
         if (order) schedule_for_grid();                          // explicit sub-box list: the caller's grid as given
-        else if (plan_tiles_mem(c, region, ndiv_in, reserve, full_yx, ndiv_eff)) return 1;
+        else if (plan_tiles_mem(c, region, ndiv_in, reserve, full_yx, full_z, ndiv_eff)) return 1;
         // fall back to cubic tiles <= 256, then to the caller's grid, when the workspace cannot be allocated after all
         for (int attempt = 0; attempt < 2 && !order; ++attempt) {
             if (ndiv_eff[0] == ndiv_in[0] && ndiv_eff[1] == ndiv_in[1] && ndiv_eff[2] == ndiv_in[2]) break;

@@ -98,7 +98,7 @@ void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, fl
 
 // periodic y/x halo of width `pad` of a tensor whose interior has been written; dst = src extended periodically in y/x
 void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s);
-void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s);
+void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s, int padz = 0);
 
 // NBE_DBG builds: per-phase cycle totals of the f16x3 3x3x3 kernel since the last call (zeros otherwise)
 void h3q_read_stamps(double* out16, hipStream_t s);

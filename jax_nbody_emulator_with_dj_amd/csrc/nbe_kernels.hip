@@ -468,26 +468,29 @@ void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s) {
                        t.pstride, t.G, t.D, t.H, t.W, pad);
 }
 
-// dst (D, Hs + 2*pad, Ws + 2*pad) = src (D, Hs, Ws) extended periodically in y and x by `pad` voxels
+// dst (D, Hs + 2*pad, Ws + 2*pad) = src (Ds, Hs, Ws) extended periodically in y and x by `pad` voxels and, when
+// padz > 0, in z by padz planes (D = Ds + 2*padz; padz = 0: D = Ds, planes map one to one)
 __global__ __launch_bounds__(256) void wrap_pad_kernel(const float* __restrict__ sx, const float* __restrict__ sdx,
-                                                       long spstride, int Hs, int Ws, float* __restrict__ dx_,
+                                                       long spstride, int Ds, int Hs, int Ws, float* __restrict__ dx_,
                                                        float* __restrict__ ddx, long dpstride, int D, int H, int W,
-                                                       int pad) {
+                                                       int pad, int padz) {
     const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= (long)D * H * W) return;
     const int z = (int)(v / ((long)H * W)), rem = (int)(v - (long)z * H * W);
     const int y = rem / W, x = rem - y * W;
     const int ys = ((y - pad) % Hs + Hs) % Hs, xs = ((x - pad) % Ws + Ws) % Ws;
-    const long sv = ((long)z * Hs + ys) * Ws + xs;
+    const int zs = ((z - padz) % Ds + Ds) % Ds;
+    const long sv = ((long)zs * Hs + ys) * Ws + xs;
     const int g = blockIdx.y;
     *(f32x4*)(dx_ + ((long)g * dpstride + v) * 4) = *(const f32x4*)(sx + ((long)g * spstride + sv) * 4);
     if (sdx) *(f32x4*)(ddx + ((long)g * dpstride + v) * 4) = *(const f32x4*)(sdx + ((long)g * spstride + sv) * 4);
 }
 
-void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s) {
+void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s, int padz) {
     const long V = dst.vox();
     hipLaunchKernelGGL(wrap_pad_kernel, dim3((unsigned)((V + 255) / 256), src.G), dim3(256), 0, s, src.x,
-                       vel ? src.dx : nullptr, src.pstride, src.H, src.W, dst.x, dst.dx, dst.pstride, dst.D, dst.H, dst.W, pad);
+                       vel ? src.dx : nullptr, src.pstride, src.D, src.H, src.W, dst.x, dst.dx, dst.pstride, dst.D, dst.H,
+                       dst.W, pad, padz);
 }
 
 template <typename OT>

@@ -256,8 +256,10 @@ def test_periodic_yx_mode_is_identical(prec, monkeypatch):
         eng.set_periodic(False)
         d0, v0 = proc.process_box(box, Z, OM, show_progress=False)
         eng.set_periodic(True)
-        for S in (-1, 32):
+        # max_tile 512: the two sub-boxes merge into the whole box (periodic in z as well); 32: two tiles, periodic in y/x
+        for S, mt in ((-1, 512), (32, 512), (-1, 32)):
             eng.set_slab(S)
+            eng.set_max_tile(mt)
             d1, v1 = proc.process_box(box, Z, OM, show_progress=False)
             if prec == "f16":                                   # float32 sums may differ in the last bit before the f16 rounding
                 assert rel_l2(d1, d0) <= 1e-3 and rel_l2(v1, v0) <= 1e-2, S
@@ -267,6 +269,7 @@ def test_periodic_yx_mode_is_identical(prec, monkeypatch):
     finally:
         eng.set_periodic(True)
         eng.set_slab(-1)
+        eng.set_max_tile(512)
 
 
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():
