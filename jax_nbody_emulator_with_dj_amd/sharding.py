@@ -66,17 +66,22 @@ def brick_extent(coords, grid, size):
     return origin, shape
 
 
-def exchange_halo(brick, grid, coords, pad=PAD, group=None):
+def exchange_halo(brick, grid, coords, pad=PAD, group=None, pad_unsplit=True):
     """brick: (C, b0, b1, b2) tensor (CPU with gloo, CUDA with nccl).  Returns the haloed
-    brick (C, b0+2p, b1+2p, b2+2p) whose halo holds the periodic neighbours' voxels."""
+    brick whose halo holds the periodic neighbours' voxels: (C, b0+2p, b1+2p, b2+2p), or with
+    pad_unsplit=False haloed only along the axes the rank grid splits -- along the others the brick
+    is the periodic box itself and the engine wraps around (and can run its periodic mode)."""
     C, b0, b1, b2 = brick.shape
     b = (b0, b1, b2)
+    pa = tuple(pad if (grid[a] > 1 or pad_unsplit) else 0 for a in range(3))
     for a in range(3):
         if b[a] < pad:
             raise ValueError("brick extent %d along axis %d is smaller than the halo %d" % (b[a], a, pad))
-    H = torch.empty((C, b0 + 2 * pad, b1 + 2 * pad, b2 + 2 * pad), dtype=brick.dtype, device=brick.device)
-    H[:, pad:pad + b0, pad:pad + b1, pad:pad + b2] = brick
+    H = torch.empty((C, b0 + 2 * pa[0], b1 + 2 * pa[1], b2 + 2 * pa[2]), dtype=brick.dtype, device=brick.device)
+    H[:, pa[0]:pa[0] + b0, pa[1]:pa[1] + b1, pa[2]:pa[2] + b2] = brick
     for a in range(3):
+        if pa[a] == 0:
+            continue
         # extents on the other axes: halos included where already filled (axes < a), centre otherwise
         def sl(lo, hi):
             idx = [slice(None)]
@@ -86,7 +91,7 @@ def exchange_halo(brick, grid, coords, pad=PAD, group=None):
                 elif k < a:
                     idx.append(slice(None))
                 else:
-                    idx.append(slice(pad, pad + b[k]))
+                    idx.append(slice(pa[k], pa[k] + b[k]))
             return tuple(idx)
         first = sl(pad, 2 * pad)                    # my first `pad` planes  -> minus neighbour's high halo
         last = sl(b[a], b[a] + pad)                 # my last  `pad` planes  -> plus  neighbour's low halo
@@ -157,7 +162,7 @@ class ShardedBox:
         if self.comm_stream is not None and interior:
             self.comm_stream.wait_stream(cur)
             with torch.cuda.stream(self.comm_stream):
-                H = exchange_halo(brick, self.grid, self.coords, PAD, self.group)
+                H = exchange_halo(brick, self.grid, self.coords, PAD, self.group, pad_unsplit=False)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream)
             # interior crops read the un-haloed brick itself (origin 0): independent of H
@@ -165,8 +170,9 @@ class ShardedBox:
             cur.wait_event(done)
             H.record_stream(cur)
         else:
-            H = exchange_halo(brick, self.grid, self.coords, PAD, self.group)
+            H = exchange_halo(brick, self.grid, self.coords, PAD, self.group, pad_unsplit=False)
             boundary = interior + boundary
-        self.eng.process_region(H, (PAD, PAD, PAD), self.bshape, nd, Dz, vel_fac, disp, vel,
-                                order=sorted(boundary))
+        # haloed only along the split axes: along the others the region is the periodic box itself
+        origin = tuple(PAD if g > 1 else 0 for g in self.grid)
+        self.eng.process_region(H, origin, self.bshape, nd, Dz, vel_fac, disp, vel, order=sorted(boundary))
         return disp, vel

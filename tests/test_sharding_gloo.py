@@ -74,7 +74,14 @@ def _worker(rank, world, port, ndiv, size, pad, q):
         # reference: periodic gather of the haloed brick from the global box (subbox.py:90-95 index rule)
         idx = [np.arange(o - pad, o + b + pad) % s for o, b, s in zip(origin, bshape, size)]
         want = full[:, idx[0][:, None, None], idx[1][None, :, None], idx[2][None, None, :]]
-        q.put((rank, bool(torch.equal(H, want)), tuple(H.shape)))
+        ok = bool(torch.equal(H, want))
+        # haloed only along the axes the rank grid splits (what ShardedBox hands to the engine)
+        H2 = S.exchange_halo(brick, grid, coords, pad, pad_unsplit=False)
+        pa = [pad if g > 1 else 0 for g in grid]
+        idx = [np.arange(o - p, o + b + p) % s for o, b, s, p in zip(origin, bshape, size, pa)]
+        want2 = full[:, idx[0][:, None, None], idx[1][None, :, None], idx[2][None, None, :]]
+        ok = ok and bool(torch.equal(H2, want2))
+        q.put((rank, ok, tuple(H.shape)))
     finally:
         dist.destroy_process_group()
 
