@@ -280,8 +280,9 @@ static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer)
 // StyleResNetBlock3DVel (style_blocks_vel.py:96-166): skip 1x1x1 cropped by 2, conv-act-conv, add, [act].
 // Periodic-yx mode (x.pad = 1): y and x do not shrink -- every 3x3x3 convolution reads its input's wrap-around halo
 // and writes the interior of a tensor of the same padded size, whose halo is filled afterwards; z shrinks as always.
+// (dst: write the block's result there -- a view with the result's geometry -- instead of allocating it)
 static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, bool final_act,
-                    int cout, int cmid, Tensor* out) {
+                    int cout, int cmid, Tensor* out, const Tensor* dst = nullptr) {
     const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
     if (!Ls || !L0 || !L1) return fail("missing layers of block %s", name);
     const int D = x.p.D, H = x.p.H, W = x.p.W, pad = x.pad;
@@ -289,9 +290,11 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     const int sy = pad ? 0 : 2;                                  // what one 3x3x3 convolution takes off y and x
     // The second convolution adds the skip as a residual and writes its result over it (every lane reads its residual
     // elements before it stores the same elements): one full-resolution tensor pair less at the workspace peak.
-    Tensor s = tallocp(c, cout, D - 4, Hi - 2 * sy, Wi - 2 * sy, pad);
+    Tensor s = dst ? *dst : tallocp(c, cout, D - 4, Hi - 2 * sy, Wi - 2 * sy, pad);
     Tensor h = tallocp(c, cmid, D - 2, Hi - sy, Wi - sy, pad);
-    if (s.off < 0 || h.off < 0) return fail("workspace exhausted in block %s", name);
+    if ((!dst && s.off < 0) || h.off < 0) return fail("workspace exhausted in block %s", name);
+    if (dst && (s.p.D != D - 4 || s.p.H != Hi - 2 * sy + 2 * pad || s.p.W != Wi - 2 * sy + 2 * pad || s.pad != pad))
+        return fail("internal: destination geometry mismatch in block %s", name);
     {
         ConvLaunch cl; cl.in = x.p; cl.in_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
         cl.Dv = D - 4; cl.Hv = Hi - 2 * sy; cl.Wv = Wi - 2 * sy; cl.out = inner(s); cl.flags = 0;
@@ -452,10 +455,12 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
         const int n = std::min(S, zhi - z);
         Tensor a, y0;
         if (resblock(c, "conv_l00", zview(tin, z, n + 8), false, true, m, m, &a)) return 1;
-        if (resblock(c, "conv_l01", a, true, true, m, m, &y0)) return 1;
+        // periodic in z: the slab is exactly planes [z - 40, z - 40 + n) of the skip connection -- write it there
+        const Tensor sv = pz ? zview(skip0, z - 40, n) : Tensor();
+        if (resblock(c, "conv_l01", a, true, true, m, m, &y0, pz ? &sv : nullptr)) return 1;
         tfree(c, a);
         const int i0 = std::max(0, 40 - z), i1 = std::min(n, Y - 40 - z);      // planes of this slab inside the crop
-        if (i1 > i0 && !c->dry) {
+        if (!pz && i1 > i0 && !c->dry) {
             Planes sp = y0.p; sp.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
             launch_crop(sp, pad ? 0 : 40, zview(skip0, z + i0 - 40, i1 - i0).p, 0, c->vel, c->stream, i0);
         }
