@@ -116,7 +116,7 @@ def main():
     if world == 1:
         data = torch.randn((3,) + size, device=dev, dtype=torch.float32, generator=gen)
     else:
-        grid = sharding.rank_grid(world, ndiv)
+        grid = sharding.rank_grid(world, ndiv, size)
         _, bshape = sharding.brick_extent(sharding.rank_coords(rank, grid), grid, size)
         data = torch.randn((3,) + bshape, device=dev, dtype=torch.float32, generator=gen)
     disp = torch.zeros_like(data)

@@ -25,30 +25,43 @@ except Exception:  # pragma: no cover
 PAD = 48
 
 
-def rank_grid(world_size, ndiv):
-    """Split `world_size` ranks over the sub-box grid `ndiv`: powers of two peel off the
-    leading axes first (2 -> (2,1,1), 4 -> (2,2,1), 8 -> (2,2,2), 16 -> (4,2,2) ...)."""
-    grid = [1, 1, 1]
+def _halo_factor(e):
+    """Work per output voxel of a padded axis of extent e relative to an axis without halo recompute (fit to the
+    measured 17.1 / 11.2 / 9.33 MFLOP per voxel of 128^3 / 256^3 / 512^3 tiles against the network's 7.93)."""
+    return 1.0 + 30.0 / e + 900.0 / (e * e)
+
+
+def rank_grid(world_size, ndiv, size=None, pad=PAD):
+    """Split `world_size` ranks over the sub-box grid `ndiv`: the factorisation with the least halo recompute.
+    A brick that is not split in y and x runs the engine's periodic mode there and pays only for its z halo;
+    otherwise every axis pays its padded factor.  512^3 / ndiv 4: 2 -> (2,1,1), 4 -> (4,1,1) (measured on one card:
+    0.84 s per brick against 0.92 s for (2,2,1)), 8 -> (2,2,2), 16 -> (4,2,2).  Ties go to the leading axes."""
     n = int(world_size)
-    ax = 0
-    guard = 0
-    while n > 1:
-        f = 2 if n % 2 == 0 else n
-        placed = False
-        for k in range(3):
-            a = (ax + k) % 3
-            if ndiv[a] % (grid[a] * f) == 0:
-                grid[a] *= f
-                ax = a + 1
-                placed = True
-                break
-        if not placed:
-            raise ValueError("cannot distribute %d ranks over a %s sub-box grid" % (world_size, tuple(ndiv)))
-        n //= f
-        guard += 1
-        if guard > 64:
-            raise ValueError("rank grid factorisation failed")
-    return tuple(grid)
+    if size is None:
+        size = tuple(128 * d for d in ndiv)
+    best, best_cost = None, None
+    for g0 in range(1, n + 1):
+        if n % g0 or ndiv[0] % g0:
+            continue
+        for g1 in range(1, n // g0 + 1):
+            if (n // g0) % g1 or ndiv[1] % g1:
+                continue
+            g2 = n // (g0 * g1)
+            if ndiv[2] % g2:
+                continue
+            e = (size[0] / g0, size[1] / g1, size[2] / g2)
+            if any(g > 1 and ee < pad for g, ee in zip((g0, g1, g2), e)):
+                continue                                  # a brick must hold its neighbour's halo
+            if g1 == 1 and g2 == 1:
+                cost = _halo_factor(e[0]) if g0 > 1 else 1.0
+            else:
+                cost = _halo_factor(e[0]) * _halo_factor(e[1]) * _halo_factor(e[2])
+            key = (round(cost, 6), -g0, -g1)
+            if best is None or key < best_cost:
+                best, best_cost = (g0, g1, g2), key
+    if best is None:
+        raise ValueError("cannot distribute %d ranks over a %s sub-box grid" % (world_size, tuple(ndiv)))
+    return best
 
 
 def rank_coords(rank, grid):
@@ -145,7 +158,7 @@ class ShardedBox:
         self.eng = engine
         self.size, self.ndiv = tuple(size), tuple(ndiv)
         self.rank, self.world = rank, world_size
-        self.grid = rank_grid(world_size, ndiv)
+        self.grid = rank_grid(world_size, ndiv, self.size)
         self.coords = rank_coords(rank, self.grid)
         self.origin, self.bshape = brick_extent(self.coords, self.grid, size)
         self.nd_local = local_ndiv(ndiv, self.grid)

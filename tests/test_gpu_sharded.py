@@ -56,7 +56,8 @@ def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q):
 
 
 @pytest.mark.parametrize("world,size,ndiv", [(2, (128, 64, 64), (2, 1, 1)),
-                                             (4, (128, 128, 64), (4, 2, 1))])
+                                             (4, (128, 128, 64), (4, 2, 1)),        # rank grid (2,2,1): y split, padded
+                                             (4, (256, 64, 64), (4, 1, 1))])        # (4,1,1): bricks periodic in y and x
 def test_sharded_equals_single_process(world, size, ndiv):
     import torch.multiprocessing as mp
     import jax_nbody_emulator_with_dj_amd as J

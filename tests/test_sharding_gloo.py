@@ -16,7 +16,8 @@ from jax_nbody_emulator_with_dj_amd import sharding as S
 def test_rank_grid_and_bricks():
     assert S.rank_grid(1, (4, 4, 4)) == (1, 1, 1)
     assert S.rank_grid(2, (4, 4, 4)) == (2, 1, 1)
-    assert S.rank_grid(4, (4, 4, 4)) == (2, 2, 1)
+    assert S.rank_grid(4, (4, 4, 4)) == (4, 1, 1)             # z-only split: the bricks stay periodic in y and x
+    assert S.rank_grid(4, (2, 4, 4)) == (1, 2, 2)             # cubes beat slabs once every axis is padded anyway
     assert S.rank_grid(8, (4, 4, 4)) == (2, 2, 2)
     assert S.rank_grid(8, (8, 8, 8)) == (2, 2, 2)
     assert S.rank_grid(16, (4, 4, 4)) == (4, 2, 2)
@@ -64,7 +65,7 @@ def _worker(rank, world, port, ndiv, size, pad, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        grid = S.rank_grid(world, ndiv)
+        grid = S.rank_grid(world, ndiv, size, pad)
         coords = S.rank_coords(rank, grid)
         origin, bshape = S.brick_extent(coords, grid, size)
         full = torch.from_numpy(np.random.default_rng(123).standard_normal((3,) + size).astype(np.float32))
