@@ -11,7 +11,7 @@ e.load_params(StyleNBodyEmulatorVelCore().init(1), False)
 e.set_cosmology(0.3, 0.77)
 N = 512
 cases = [("N=2 (2,1,1)", (2, 1, 1)), ("N=4 (2,2,1)", (2, 2, 1)), ("N=4 (4,1,1)", (4, 1, 1)),
-         ("N=8 (2,2,2)", (2, 2, 2)), ("N=8 (8,1,1)", (8, 1, 1)), ("N=8 (4,2,1)", (4, 2, 1))]
+         ("N=8 (2,2,2)", (2, 2, 2)), ("N=8 (4,2,1)", (4, 2, 1))]
 for name, grid in cases:
     b = tuple(N // g for g in grid)
     pa = tuple(48 if g > 1 else 0 for g in grid)
