@@ -664,7 +664,12 @@ __global__ __launch_bounds__(512, 2) void conv_h3p_kernel(ConvKArgs a) {
 constexpr int HQ_TAPU = 4 * 64;                           // 16-byte units per tap and set
 constexpr int HQ_WA = 5 * HQ_TAPU, HQ_WB = 4 * HQ_TAPU;   // units per set in weight buffer A (taps 0-4) / B (taps 5-8)
 constexpr int HQ_OFF_B = 2 * HQ_WA;                       // buffer B follows buffer A
-constexpr int HQ_XT = 4 * HP_PL;                          // units of one tensor's patch (hi/lo x two channel halves)
+// LDS pitch of a patch plane: 340 valid units padded to a multiple of 8, so that the planes 2*kh a ds_read_b128 mixes in
+// one LDS cycle (lanes of two 16-lane rows) start 0 mod 16 units apart and hit 16 distinct bank quads.  With 340 the
+// rows were 8 mod 16 apart and every activation read was a 2-way bank conflict (SQ_LDS_BANK_CONFLICT = 40 % of
+// SQ_LDS_IDX_ACTIVE).
+constexpr int HQ_PP = (HP_PL + 7) / 8 * 8;                // 344
+constexpr int HQ_XT = 4 * HQ_PP;                          // units of one tensor's patch (hi/lo x two channel halves)
 constexpr int HQ_XB = 2 * HQ_XT;                          // one patch buffer: X, dX
 constexpr int HQ_XBASE = HQ_OFF_B + 2 * HQ_WB;
 constexpr int HQ_LDS_UNITS = HQ_XBASE + 2 * HQ_XB;        // 10048 units = 160,768 B
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         const int n = wave + 8 * t, pl = n / 6, k = n - 6 * pl;
         if (xval[t])
             dma16s((const char*)(tensor ? a.dx : a.x) + xo + (long)pl * a.in_pstride * 16, xoff[t],
-                   lds + HQ_XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HP_PL + k * 64);
+                   lds + HQ_XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HQ_PP + k * 64);
     };
 
     f32x4 ym[8], yc[8], dm[8], dc[8];
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     // ---- operands.  A (2 MFMA row tiles): unit (tap, 2*kh + part) of the stage's weight buffer, row 32*it + 16*mt + c.
     // B (4 column tiles): patch plane 2*kh + part, position (2*jq + jt, 16*nh + c) shifted by this lane group's tap.
     const int aP = (ks * 4 + 2 * kh) * 64 + 32 * it + c;
-    const int bB = (2 * kh) * HP_PL + (2 * jq) * HP_RS + c;
+    const int bB = (2 * kh) * HQ_PP + (2 * jq) * HP_RS + c;
     const int bP1 = bB + ks, bP32 = bB + 32 * ks;               // second tap of the pair: one column / 32 units further
     auto LA = [&](half8 (&r)[2], int idx) {
         r[0] = L8[idx];
@@ -819,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         LB(dxh, xp + HQ_XT);
         NBE_SB; MM8(dc, dwl, xh, kind, 6, g, gn, xo, nb, px); NBE_SB;
         MM8(yc, wl, xh, 0, 0, g, gn, xo, nb, px); NBE_SB;
-        LB(dxl, xp + HQ_XT + HP_PL);
+        LB(dxl, xp + HQ_XT + HQ_PP);
         NBE_SB; MM8(ym, wh, xh, 0, 0, g, gn, xo, nb, px); NBE_SB;
         pre6();
         NBE_SB; MM8(dc, wl, dxh, 0, 0, g, gn, xo, nb, px); NBE_SB;
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         for (int t = 0; t < 5; ++t) dma_w(0, 0, t);
         __syncthreads();
         NBE_STAMP(0)
-        LB(xl, HQ_XBASE + bP1 + HP_PL);
+        LB(xl, HQ_XBASE + bP1 + HQ_PP);
         LB(xh, HQ_XBASE + bP1);
     }
 
@@ -860,13 +865,13 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         // single tap 4 = (dy 1, dx 1): lane group halves select the PART (a1*, b1*) or the TENSOR / weight set (a2, b2)
         const int aS1 = 4 * HQ_TAPU + (2 * kh + ks) * 64 + 32 * it + c;
         const int aS2 = 4 * HQ_TAPU + (2 * kh) * 64 + (ks ? 0 : HQ_WA) + 32 * it + c;
-        const int bS1 = xb + (2 * kh + 1 - ks) * HP_PL + (2 * jq) * HP_RS + c + SH4;
-        const int bS2 = xb + (2 * kh) * HP_PL + (ks ? HQ_XT : 0) + (2 * jq) * HP_RS + c + SH4;
+        const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + (2 * jq) * HP_RS + c + SH4;
+        const int bS2 = xb + (2 * kh) * HQ_PP + (ks ? HQ_XT : 0) + (2 * jq) * HP_RS + c + SH4;
 
         // ======== first stage: taps (0,1) (2,3) [4] from weight buffer A
         LA(dwh, HQ_WA + aP);
         pair(1, g, gn, xo, nb, px, 0, HQ_WA, xb + bP1,
-             [&] { LA(dwh, 2 * HQ_TAPU + HQ_WA + aP); LB(xl, xb + 2 + bP32 + HP_PL); },
+             [&] { LA(dwh, 2 * HQ_TAPU + HQ_WA + aP); LB(xl, xb + 2 + bP32 + HQ_PP); },
              [&] { LB(xh, xb + 2 + bP32); });
         pair(0, g, gn, xo, nb, px, 2 * HQ_TAPU, HQ_WA, xb + 2 + bP32,
              [&] { LA(a1d, aS1 + HQ_WA); LB(b1x, bS1); },
@@ -882,7 +887,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         NBE_SB; MM8(yc, a1w, b1x, 0, 0, g, gn, xo, nb, px); NBE_SB;          // wh.xl + wl.xh
         LB(b1d, bS1 + HQ_XT);
         NBE_SB; MM8(ym, a0, b1x, 0, 0, g, gn, xo, nb, px); NBE_SB;           // wh.xh
-        LB(xl, xb + SH5 + bP32 + HP_PL);                                 // x of taps (5,6): this group's patch
+        LB(xl, xb + SH5 + bP32 + HQ_PP);                                 // x of taps (5,6): this group's patch
         NBE_SB; MM8(dm, a2, b2, 0, 0, g, gn, xo, nb, px); NBE_SB;            // dwh.xh + wh.dxh
         LB(xh, xb + SH5 + bP32);
         NBE_SB; MM8(dc, a1w, b1d, 0, 0, g, gn, xo, nb, px); NBE_SB;          // wh.dxl + wl.dxh
@@ -891,10 +896,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         // ======== second stage: taps (5,6) (7,8) from weight buffer B
         LA(dwh, HQ_OFF_B + HQ_WB + aP);
         pair(2, g, gn, xo, nb, px, HQ_OFF_B, HQ_WB, xb + SH5 + bP32,
-             [&] { LA(dwh, HQ_OFF_B + 2 * HQ_TAPU + HQ_WB + aP); LB(xl, xb + SH7 + bP1 + HP_PL); },
+             [&] { LA(dwh, HQ_OFF_B + 2 * HQ_TAPU + HQ_WB + aP); LB(xl, xb + SH7 + bP1 + HQ_PP); },
              [&] { LB(xh, xb + SH7 + bP1); });
         pair(0, g, gn, xo, nb, px, HQ_OFF_B + 2 * HQ_TAPU, HQ_WB, xb + SH7 + bP1,
-             [&] { if (px) LB(xl, xbn + bP1 + HP_PL); },         // x of taps (0,1) of the next group: landed above
+             [&] { if (px) LB(xl, xbn + bP1 + HQ_PP); },         // x of taps (0,1) of the next group: landed above
              [&] { if (px) LB(xh, xbn + bP1); });
         NBE_STAGE_END(4, 0)                                      // buffer A and both patches of g+1 have landed
     }
@@ -1012,7 +1017,10 @@ static void launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
 // patch planes p = 2*h + part (SPLIT) or 2*tensor + h, 18 x 34 units each.
 constexpr int H2_ROWS = 16;
 constexpr int H2_PL = (H2_ROWS + 2) * HP_RS;              // units per patch plane: 612
-constexpr int H2_XB = 4 * H2_PL;                          // one patch buffer: 4 planes
+// LDS pitch of a patch plane, padded so that the two planes a ds_read_b128 mixes in one LDS cycle start 0 mod 16 units
+// apart (no bank conflicts): planes 2*kh apart in the SPLIT variant (pitch multiple of 8), kh apart otherwise (of 16)
+constexpr int H2_PP = 624;
+constexpr int H2_XB = 4 * H2_PP;                          // one patch buffer: 4 planes
 constexpr int H2_TAPU = 4 * 64;                           // units per tap (all rows)
 constexpr int H2_WA = 5 * H2_TAPU, H2_WB = 4 * H2_TAPU;
 constexpr int H2_OFF_B = H2_WA;
@@ -1072,7 +1080,7 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
         if (xval[t]) {
             const char* base = SPLIT ? (const char*)a.x + (long)pl * a.in_pstride * 16
                                      : (const char*)((pl >> 1) ? a.dx : a.x) + (long)(pl & 1) * a.in_pstride * 16;
-            dma16s(base + xo, xoff[t], lds + H2_XBASE + buf * H2_XB + pl * H2_PL + k * 64);
+            dma16s(base + xo, xoff[t], lds + H2_XBASE + buf * H2_XB + pl * H2_PP + k * 64);
         }
     };
 
@@ -1087,10 +1095,10 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
 
     // ---- operands
     constexpr int A1OFF = SPLIT ? 64 : 128;                      // a1 = a0 + one row (lo part) / two rows (dw set)
-    constexpr int B1OFF = SPLIT ? H2_PL : 2 * H2_PL;             // b1 = b0 + one plane (lo part) / two planes (dx tensor)
+    constexpr int B1OFF = SPLIT ? H2_PP : 2 * H2_PP;             // b1 = b0 + one plane (lo part) / two planes (dx tensor)
     const int rowA = SPLIT ? 2 * kh : kh;
     const int aP = (ks * 4 + rowA) * 64 + 32 * it + c;           // pair: tap ks of the pair, row of a0
-    const int bB = rowA * H2_PL + (4 * jq) * HP_RS + c;          // plane of b0 (same index rule as the weight row)
+    const int bB = rowA * H2_PP + (4 * jq) * HP_RS + c;          // plane of b0 (same index rule as the weight row)
     const int bP1 = bB + ks, bP32 = bB + 32 * ks;
     auto LA = [&](half8 (&r)[2], int idx) {
         r[0] = L8[idx];
@@ -1160,7 +1168,7 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
         half8 as[2], am[2], bsa[4], bsb[4];
         const int aS = 4 * H2_TAPU + (SPLIT ? (2 * kh + ks) : (kh + 2 * ks)) * 64 + 32 * it + c;     // [a0 | a1]
         const int aM = 4 * H2_TAPU + rowA * 64 + 32 * it + c;                                       // a0 for both halves
-        const int bS = xb + (rowA + (1 - ks) * (SPLIT ? 1 : 2)) * H2_PL + (4 * jq) * HP_RS + c + SH4;   // [b1 | b0]
+        const int bS = xb + (rowA + (1 - ks) * (SPLIT ? 1 : 2)) * H2_PP + (4 * jq) * HP_RS + c + SH4;   // [b1 | b0]
 
         // ======== first stage: taps (0,1) (2,3) [4] from weight buffer A
         LA(a0x, aP); LB(b1, xb + bP1 + B1OFF, 0); LB(b0a, xb + bP1, 0);
