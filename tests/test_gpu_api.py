@@ -266,6 +266,17 @@ def test_periodic_yx_mode_is_identical(prec, monkeypatch):
             else:
                 _close(d1, d0, 1e-6, 1e-5, "periodic-yx disp S=%d" % S)
                 _close(v1, v0, 1e-6, 1e-5, "periodic-yx vel S=%d" % S)
+        # float16 outputs go through the same pad-aware head
+        proc16 = J.SubboxProcessor(m, p, J.SubboxConfig(size=size, ndiv=ndiv, output_dtype=np.float16))
+        eng.set_slab(-1); eng.set_max_tile(512)
+        h1, w1 = proc16.process_box(box, Z, OM, show_progress=False)
+        eng.set_periodic(False)
+        h0, w0 = proc16.process_box(box, Z, OM, show_progress=False)
+        assert h1.dtype == np.float16
+        if prec == "f16":
+            assert rel_l2(h1.astype(np.float32), h0.astype(np.float32)) <= 2e-3
+        else:
+            assert np.array_equal(h1, h0) and np.array_equal(w1, w0)
     finally:
         eng.set_periodic(True)
         eng.set_slab(-1)
