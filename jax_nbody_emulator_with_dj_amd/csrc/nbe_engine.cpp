@@ -332,6 +332,7 @@ static int downblock(nbe_ctx* c, const char* name, const Tensor& x, Tensor* out)
 static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& cat, int xcrop = 0) {
     const Layer* L = find_layer(c, name, "conv_0");
     if (!L) return fail("missing layer %s/conv_0", name);
+    xcrop += x.pad;                                              // a periodic halo of x is not up-sampled either
     const int Hx = x.p.H - 2 * xcrop, Wx = x.p.W - 2 * xcrop;
     if (cat.p.D != 2 * x.p.D || cat.p.H - 2 * cat.pad != 2 * Hx || cat.p.W - 2 * cat.pad != 2 * Wx)
         return fail("internal: concat geometry mismatch in %s", name);
@@ -476,21 +477,42 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
         }
         tfree(c, y0);
     }
+    // Level 1.  Periodic-yx: it runs periodic in y and x as well -- its input is the interior result of down_l0 with a
+    // 1-voxel wrap-around halo (and, periodic in z, 22 planes of periodic context); level 2 and below keep the padded
+    // scheme: down_l1 runs on the interior and is extended periodically by the 10 voxels those levels consume.
     Tensor t = td;
     if (pad) {
-        t = talloc(c, m, td.p.D + (pz ? 44 : 0), td.p.H + 44, td.p.W + 44);
+        t = tallocp(c, m, td.p.D + (pz ? 44 : 0), td.p.H, td.p.W, 1);
         if (t.off < 0) return fail("workspace exhausted (level 1 input)");
-        if (!c->dry) launch_wrap_pad(td.p, t.p, 22, c->vel, c->stream, pz ? 22 : 0);
+        if (!c->dry) launch_wrap_pad(td.p, t.p, 1, c->vel, c->stream, pz ? 22 : 0);
         tfree(c, td);
     }
 
     Tensor y1, y2, cat1, cat2, r;
     if (resblock(c, "conv_l1", t, true, true, m, m, &y1)) return 1;
     tfree(c, t);
-    cat1 = talloc(c, 2 * m, y1.p.D - 32, y1.p.H - 32, y1.p.W - 32);
-    if (cat1.off < 0) return fail("workspace exhausted (cat1)");
-    crop_into(c, y1, 16, cat1);
-    if (downblock(c, "down_l1", y1, &t)) return 1;
+    if (pad) {
+        cat1 = tallocp(c, 2 * m, y1.p.D - 32, y1.p.H - 2, y1.p.W - 2, 1);
+        if (cat1.off < 0) return fail("workspace exhausted (cat1)");
+        if (!c->dry) {
+            Planes sp = y1.p; sp.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
+            launch_crop(sp, 0, cat1.p, 0, c->vel, c->stream, 16);
+        }
+        Tensor t2 = talloc(c, m, y1.p.D / 2, (y1.p.H - 2) / 2, (y1.p.W - 2) / 2);
+        const Layer* Ld1 = find_layer(c, "down_l1", "conv_0");
+        if (t2.off < 0 || !Ld1) return fail("workspace exhausted or missing layer (down_l1)");
+        ConvLaunch cl; cl.in = inner(y1); cl.Dv = t2.p.D; cl.Hv = t2.p.H; cl.Wv = t2.p.W; cl.out = t2.p; cl.flags = F_ACT;
+        run_conv(c, *Ld1, cl, true);
+        t = talloc(c, m, t2.p.D, t2.p.H + 20, t2.p.W + 20);
+        if (t.off < 0) return fail("workspace exhausted (level 2 input)");
+        if (!c->dry) launch_wrap_pad(t2.p, t.p, 10, c->vel, c->stream, 0);
+        tfree(c, t2);
+    } else {
+        cat1 = talloc(c, 2 * m, y1.p.D - 32, y1.p.H - 32, y1.p.W - 32);
+        if (cat1.off < 0) return fail("workspace exhausted (cat1)");
+        crop_into(c, y1, 16, cat1);
+        if (downblock(c, "down_l1", y1, &t)) return 1;
+    }
     tfree(c, y1);
     if (resblock(c, "conv_l2", t, true, true, m, m, &y2)) return 1;
     tfree(c, t);
@@ -505,13 +527,14 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     tfree(c, r);
     if (resblock(c, "conv_r2", cat2, true, true, m, 2 * m, &r)) return 1;
     tfree(c, cat2);
-    if (upblock(c, "up_r1", r, cat1)) return 1;
+    // periodic-yx: the level-2 result carries 2 voxels of y/x context that the periodic level 1 does not need
+    if (upblock(c, "up_r1", r, cat1, pad ? 2 : 0)) return 1;
+    fill_halo(c, cat1);
     tfree(c, r);
     if (resblock(c, "conv_r1", cat1, true, true, m, 2 * m, &r)) return 1;      // r: level-1 decoder output
     tfree(c, cat1);
-    // periodic-yx: the level-1 result carries 2 voxels of y/x context that the full-resolution decoder does not need
-    const int rcrop = pad ? 2 : 0;
-    if (2 * r.p.D != skip0.p.D || 2 * (r.p.H - 2 * rcrop) != skip0.p.H - 2 * pad || 2 * (r.p.W - 2 * rcrop) != skip0.p.W - 2 * pad)
+    const int rcrop = 0;
+    if (2 * r.p.D != skip0.p.D || 2 * (r.p.H - 2 * r.pad) != skip0.p.H - 2 * pad || 2 * (r.p.W - 2 * r.pad) != skip0.p.W - 2 * pad)
         return fail("internal: level-0 concat geometry mismatch");
 
     const int Yo = skip0.p.D - 8;                                 // output planes (= D - 96)
