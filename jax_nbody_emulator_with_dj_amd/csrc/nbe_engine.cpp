@@ -316,6 +316,41 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     return 0;
 }
 
+// The z-slab schedule's residual block: the same three launches as resblock() on plane ranges of persistent tensors.
+// Plane indices are in block-input coordinates (result plane j is centred on input plane j + 2): hidden planes
+// [jh, jh + nh) and result planes [js, js + ns) are computed; what precedes them was carried over from the slab
+// before.  h and s have the geometry resblock() would give them (s also serves as the skip / residual, in place).
+static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& h, const Tensor& s,
+                         int js, int ns, int jh, int nh, bool has_dx, bool final_act) {
+    const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
+    if (!Ls || !L0 || !L1) return fail("missing layers of block %s", name);
+    const int H = x.p.H, W = x.p.W, pad = x.pad;
+    const Tensor sv = zview(s, js, ns), hv = zview(h, jh, nh);
+    {
+        ConvLaunch cl; cl.in = zview(x, js, ns + 4).p; cl.in_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
+        cl.Dv = ns; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(sv); cl.flags = 0;
+        run_conv(c, *Ls, cl, has_dx);
+    }
+    {
+        ConvLaunch cl; cl.in = zview(x, jh, nh + 2).p; cl.Dv = nh; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = inner(hv); cl.flags = F_ACT;
+        run_conv(c, *L0, cl, has_dx);
+    }
+    fill_halo(c, hv);
+    {
+        ConvLaunch cl; cl.in = zview(h, js, ns + 2).p; cl.Dv = ns; cl.Hv = h.p.H - 2; cl.Wv = h.p.W - 2; cl.out = inner(sv);
+        cl.res = inner(sv); cl.flags = F_RES | (final_act ? F_ACT : 0);
+        run_conv(c, *L1, cl, true);
+    }
+    fill_halo(c, sv);
+    return 0;
+}
+
+// planes [src, src + n) of t -> planes [dst, dst + n) of the same tensor (the ranges must not overlap)
+static void carry_planes(nbe_ctx* c, const Tensor& t, int src, int dst, int n) {
+    if (c->dry || n <= 0) return;
+    launch_crop(zview(t, src, n).p, 0, zview(t, dst, n).p, 0, c->vel, c->stream, 0);
+}
+
 static int downblock(nbe_ctx* c, const char* name, const Tensor& x, Tensor* out) {
     const Layer* L = find_layer(c, name, "conv_0");
     if (!L) return fail("missing layer %s/conv_0", name);
@@ -452,14 +487,32 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     if (skip0.off < 0 || td.off < 0) return fail("workspace exhausted (level 0)");
     const Layer* Ld = find_layer(c, "down_l0", "conv_0");
     if (!Ld) return fail("missing layer down_l0/conv_0");
+    // Persistent slab tensors of the level-0 encoder: hidden and result of conv_l00 (h0, a), hidden of conv_l01 (h1)
+    // and, unless the slabs land in the skip tensor directly, its result (y0).  Consecutive slabs overlap by 6 / 4 / 2
+    // planes of h0 / a / h1: those are carried over from the slab before (a copy of a few planes) instead of being
+    // recomputed, so every layer computes every plane exactly once.
+    const int sy = pad ? 0 : 2;
+    Tensor h0 = tallocp(c, m, S + 6, Hi - sy, Wi - sy, pad), a = tallocp(c, m, S + 4, Hi - 2 * sy, Wi - 2 * sy, pad);
+    Tensor h1 = tallocp(c, m, S + 2, Hi - 3 * sy, Wi - 3 * sy, pad);
+    Tensor y0r = pz ? Tensor() : tallocp(c, m, S, Hi - 4 * sy, Wi - 4 * sy, pad);
+    if (h0.off < 0 || a.off < 0 || h1.off < 0 || (!pz && y0r.off < 0)) return fail("workspace exhausted (level-0 encoder slabs)");
     for (int z = zlo; z < zhi; z += S) {
         const int n = std::min(S, zhi - z);
-        Tensor a, y0;
-        if (resblock(c, "conv_l00", zview(tin, z, n + 8), false, true, m, m, &a)) return 1;
+        const bool first = z == zlo;
         // periodic in z: the slab is exactly planes [z - 40, z - 40 + n) of the skip connection -- write it there
-        const Tensor sv = pz ? zview(skip0, z - 40, n) : Tensor();
-        if (resblock(c, "conv_l01", a, true, true, m, m, &y0, pz ? &sv : nullptr)) return 1;
-        tfree(c, a);
+        const Tensor y0 = pz ? zview(skip0, z - 40, n) : zview(y0r, 0, n);
+        if (first) {
+            if (resblock_part(c, "conv_l00", zview(tin, z, n + 8), h0, a, 0, n + 4, 0, n + 6, false, true)) return 1;
+            if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 0, n + 2, true, true)) return 1;
+        } else {
+            if (resblock_part(c, "conv_l00", zview(tin, z, n + 8), h0, a, 4, n, 6, n, false, true)) return 1;
+            if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 2, n, true, true)) return 1;
+        }
+        if (z + S < zhi) {                                       // what the next slab will not recompute
+            carry_planes(c, h0, n, 0, 6);
+            carry_planes(c, a, n, 0, 4);
+            carry_planes(c, h1, n, 0, 2);
+        }
         const int i0 = std::max(0, 40 - z), i1 = std::min(n, Y - 40 - z);      // planes of this slab inside the crop
         if (!pz && i1 > i0 && !c->dry) {
             Planes sp = y0.p; sp.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
@@ -475,8 +528,9 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
                 run_conv(c, *Ld, cl, true);
             }
         }
-        tfree(c, y0);
     }
+    tfree(c, h0); tfree(c, a); tfree(c, h1);
+    if (!pz) tfree(c, y0r);
     // Level 1.  Periodic-yx: it runs periodic in y and x as well -- its input is the interior result of down_l0 with a
     // 1-voxel wrap-around halo (and, periodic in z, 22 planes of periodic context); level 2 and below keep the padded
     // scheme: down_l1 runs on the interior and is extended periodically by the 10 voxels those levels consume.
@@ -538,23 +592,36 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
         return fail("internal: level-0 concat geometry mismatch");
 
     const int Yo = skip0.p.D - 8;                                 // output planes (= D - 96)
+    // Persistent slab tensors of the level-0 decoder, with the same carry-over of the overlaps (8 / 6 / 4 / 2 planes of
+    // the concat tensor, the hidden and the result of conv_r00, the hidden of conv_r01).
+    const int Hs = skip0.p.H - 2 * pad, Ws = skip0.p.W - 2 * pad;
+    Tensor cat = tallocp(c, 2 * m, S + 8, Hs, Ws, pad), hq = tallocp(c, 2 * m, S + 6, Hs - sy, Ws - sy, pad);
+    Tensor q = tallocp(c, m, S + 4, Hs - 2 * sy, Ws - 2 * sy, pad), hy = tallocp(c, m, S + 2, Hs - 3 * sy, Ws - 3 * sy, pad);
+    Tensor y = tallocp(c, c->out_chan, S, Hs - 4 * sy, Ws - 4 * sy, pad);
+    if (cat.off < 0 || hq.off < 0 || q.off < 0 || hy.off < 0 || y.off < 0) return fail("workspace exhausted (level-0 decoder slabs)");
     for (int z = 0; z < Yo; z += S) {
         const int n = std::min(S, Yo - z);
-        Tensor cat = tallocp(c, 2 * m, n + 8, skip0.p.H - 2 * pad, skip0.p.W - 2 * pad, pad), q, y;
-        if (cat.off < 0) return fail("workspace exhausted (cat0 slab)");
-        if (!c->dry) {
-            Planes sp = zview(skip0, z, n + 8).p;
-            launch_crop(sp, 0, cat.p, 0, c->vel, c->stream, 0);
+        const bool first = z == 0;
+        const int c0 = first ? 0 : 8, cn = first ? n + 8 : n;     // new planes of the concat tensor: [c0, c0 + cn)
+        if (!c->dry) launch_crop(zview(skip0, z + c0, cn).p, 0, zview(cat, c0, cn).p, 0, c->vel, c->stream, 0);
+        if (upblock(c, "up_r0", zview(r, (z + c0) / 2, cn / 2), zview(cat, c0, cn), rcrop)) return 1;
+        fill_halo(c, zview(cat, c0, cn));
+        if (first) {
+            if (resblock_part(c, "conv_r00", cat, hq, q, 0, n + 4, 0, n + 6, true, true)) return 1;
+            if (resblock_part(c, "conv_r01", q, hy, y, 0, n, 0, n + 2, true, false)) return 1;
+        } else {
+            if (resblock_part(c, "conv_r00", cat, hq, q, 4, n, 6, n, true, true)) return 1;
+            if (resblock_part(c, "conv_r01", q, hy, y, 0, n, 2, n, true, false)) return 1;
         }
-        if (upblock(c, "up_r0", zview(r, z / 2, (n + 8) / 2), cat, rcrop)) return 1;
-        fill_halo(c, cat);
-        if (resblock(c, "conv_r00", cat, true, true, m, 2 * m, &q)) return 1;
-        tfree(c, cat);
-        if (resblock(c, "conv_r01", q, true, false, c->out_chan, m, &y)) return 1;
-        tfree(c, q);
-        run_head(c, y, zview(tin, z, n + 96), ho, z);
-        tfree(c, y);
+        if (z + S < Yo) {
+            carry_planes(c, cat, n, 0, 8);
+            carry_planes(c, hq, n, 0, 6);
+            carry_planes(c, q, n, 0, 4);
+            carry_planes(c, hy, n, 0, 2);
+        }
+        run_head(c, zview(y, 0, n), zview(tin, z, n + 96), ho, z);
     }
+    tfree(c, cat); tfree(c, hq); tfree(c, q); tfree(c, hy); tfree(c, y);
     tfree(c, r); tfree(c, skip0);
     return 0;
 }
