@@ -23,7 +23,7 @@ extern "C" {
 typedef struct nbe_ctx nbe_ctx;
 
 /* progress callback of nbe_process_box: replaces the tqdm bar of src/jax_nbody_emulator/subbox.py:186-193 */
-typedef void (*nbe_progress_cb)(int done, int total, void* user);
+typedef void (*nbe_progress_cb)(int done, int total, void* user);   /* done / total = fraction of the box finished */
 
 /* One convolution layer of the parameter tree {'params': {block: {layer: {...}}}}
  * (leaf shapes: tests/test_style_nbody_emulator_vel_core.py:408-419, style_layers_vel.py:55-75;

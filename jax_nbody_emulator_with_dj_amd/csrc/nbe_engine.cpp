@@ -98,6 +98,8 @@ struct nbe_ctx {
     bool pyx = false;                             // current tile runs in periodic-yx mode (it spans the periodic box in y and x)
     bool pyx_allowed = true;                      // env NBE_PERIODIC=0 turns the mode off
     bool pz = false;                              // ... and the tile also spans the box in z (only with pyx)
+    // progress inside a tile (z-slab schedule): tile k of n, reported in thousandths of a tile
+    nbe_progress_cb prog_cb = nullptr; void* prog_user = nullptr; int prog_k = 0, prog_n = 1;
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     // device-resident boxes of process_box
@@ -620,6 +622,10 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
             carry_planes(c, hy, n, 0, 2);
         }
         run_head(c, zview(y, 0, n), zview(tin, z, n + 96), ho, z);
+        if (c->prog_cb && !c->dry && z + n < Yo) {               // the tile's last slab is reported by the sub-box loop
+            (void)hipStreamSynchronize(c->stream);
+            c->prog_cb(c->prog_k * 1000 + (int)(1000L * (z + n) / Yo), c->prog_n * 1000, c->prog_user);
+        }
     }
     tfree(c, cat); tfree(c, hq); tfree(c, q); tfree(c, hy); tfree(c, y);
     tfree(c, r); tfree(c, skip0);
@@ -1187,11 +1193,13 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         if (idx < 0 || idx >= total) return fail("sub-box index %d out of range (0..%d)", idx, total - 1);
         // subbox.py:60-66: row-major over ndiv, last axis fastest
         const int a0 = (idx / (ndiv[1] * ndiv[2])) * c0, a1 = ((idx / ndiv[2]) % ndiv[1]) * c1, a2 = (idx % ndiv[2]) * c2;
+        c->prog_cb = cb; c->prog_user = user; c->prog_k = k; c->prog_n = n;
         if (run_subbox(c, bd, S0, S1, S2, (int)origin[0] + a0 - 48, (int)origin[1] + a1 - hal, (int)origin[2] + a2 - hal,
                        D, H, W, Dz, vel_fac, dd, vd, out_dtype, O0, O1, O2,
                        (int)oorigin[0] + a0, (int)oorigin[1] + a1, (int)oorigin[2] + a2)) return 1;
-        if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb(k + 1, n, user); }
+        if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb((k + 1) * 1000, n * 1000, user); }
     }
+    c->prog_cb = nullptr;
     HIPCHK(hipGetLastError());
     if (!out_dev) {
         HIPCHK(hipMemcpyAsync(disp, dd, out_bytes, hipMemcpyDeviceToHost, c->stream));

@@ -235,6 +235,12 @@ def test_z_slab_schedule_is_identical():
             eng.set_slab(S)
             d1, v1 = proc.process_box(box, Z, OM, show_progress=False)
             assert np.array_equal(d1, d0) and np.array_equal(v1, v0), S
+        # progress is reported per slab inside a tile: monotone, several steps per tile, ends at total
+        seen = []
+        eng.set_slab(32)
+        eng.process_box(box, size, ndiv, ((48, 48),) * 3, 0.7, 0.5, progress=lambda d, t, u: seen.append((d, t)))
+        frac = [d / t for d, t in seen]
+        assert frac == sorted(frac) and frac[-1] == 1.0 and len(seen) >= 4, seen
     finally:
         eng.set_slab(-1)
 
