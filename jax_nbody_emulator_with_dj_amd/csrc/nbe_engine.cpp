@@ -75,6 +75,11 @@ struct Layer {
     float *weight = nullptr, *sw = nullptr, *sb = nullptr;   // raw style parameters (device)
     float *wn = nullptr, *dwn = nullptr;          // modulated OIDHW (device)
     PackedW pw;
+    // tangent gauge (f16x3 style path, see conv_h3g_kernel): dw = w_n (.) (alpha[ci] + beta[co])
+    float *alpha = nullptr, *beta = nullptr;      // this layer's own factors (device; cin / cout entries, zero-padded)
+    const float* gout = nullptr;                  // gauge of the output tensor = alpha of its 3x3x3 consumer (+ channel offset)
+    const float* a_in = nullptr;                  // general kernels: gauge of the input tensor, folded into dw
+    bool g6 = false;                              // 3x3x3 layer whose input arrives in its own gauge: two products, no dw
 };
 
 struct ProfEntry { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
@@ -102,6 +107,9 @@ struct nbe_ctx {
     nbe_progress_cb prog_cb = nullptr; void* prog_user = nullptr; int prog_k = 0, prog_n = 1;
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
+    bool gauge = false;                           // the loaded network is wired for gauged tangents (style, vel, f16x3)
+    bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
+    int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
     // device-resident boxes of process_box
     float* box_in = nullptr; int64_t box_in_bytes = 0;
     char* box_out = nullptr; int64_t box_out_bytes = 0;
@@ -233,10 +241,11 @@ static void prof_collect(nbe_ctx* c) {
     c->pending.clear();
 }
 
-static std::string conv_name(const PackedW& pw, bool vel, bool has_dx) {
+static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false) {
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
     char b[96];
-    if (prec_is_half(pw.prec))
+    if (g6) snprintf(b, sizeof b, "conv_h3g<%s,vel,dx>", m);
+    else if (prec_is_half(pw.prec))
         snprintf(b, sizeof b, "%s<%s,%s,%s>", pw.prec == PREC_F16 ? "conv_h1" : "conv_h3", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx");
     else
         snprintf(b, sizeof b, "conv_mfma<%s,%s,%s,ni%d>", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx", pw.ni);
@@ -250,9 +259,11 @@ static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool h
     // timing experiments of NBE_DBG builds (bits >= 8); production kernels ignore them
     static const int dbgf = getenv("NBE_DEBUG_FLAGS") ? atoi(getenv("NBE_DEBUG_FLAGS")) & 0xF00 : 0;
     cl.flags |= dbgf;
+    const bool g6 = c->gauge_active && L.g6 && has_dx;
+    if (c->gauge_active) { cl.gout = L.gout; cl.beta = g6 ? L.beta : nullptr; }
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
-        pe = prof_entry(c, conv_name(L.pw, c->vel, has_dx));
+        pe = prof_entry(c, conv_name(L.pw, c->vel, has_dx, g6));
         ea = get_event(c); eb = get_event(c);
         (void)hipEventRecord(ea, c->stream);
     }
@@ -260,10 +271,11 @@ static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool h
     if (c->prof) {
         (void)hipEventRecord(eb, c->stream);
         c->pending.push_back({pe, ea, eb});
-        // algorithmic FLOPs: 2*MAC over valid outputs; x3 with tangent (x2 when the input has no tangent)
+        // algorithmic FLOPs: 2*MAC over valid outputs; x3 with tangent (x2 when the input has no tangent, and for
+        // the gauged form W.x, W.dx~)
         const double nout = (double)cl.Dv * cl.Hv * cl.Wv;
         const int taps = L.kind == 0 ? 27 : L.kind == 2 ? 8 : 1;
-        const double gemms = c->vel ? (has_dx ? 3.0 : 2.0) : 1.0;
+        const double gemms = c->vel ? ((has_dx && !g6) ? 3.0 : 2.0) : 1.0;
         c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.cin * taps * gemms;
         c->prof_entries[pe].launches += 1;
         if (c->pending.size() > 4096) prof_collect(c);
@@ -699,9 +711,10 @@ static void free_layers(nbe_ctx* c) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
         (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias);
+        (void)hipFree(L.alpha); (void)hipFree(L.beta);
     }
     c->layers.clear();
-    c->have_weights = false; c->modulated = false;
+    c->have_weights = false; c->modulated = false; c->gauge = false; c->gauge_active = false;
 }
 
 static int kind_of(const nbe_layer_desc& d, int* kind) {
@@ -732,6 +745,49 @@ static int expected_shape(nbe_ctx* c, const std::string& blk, const std::string&
 
 static const char* kBlocks[15] = {"conv_l00", "conv_l01", "down_l0", "conv_l1", "down_l1", "conv_l2", "down_l2", "conv_c",
                                   "up_r2", "conv_r2", "up_r1", "conv_r1", "up_r0", "conv_r00", "conv_r01"};
+
+// Tangent gauges of the style path (conv_h3g_kernel): every tensor with a tangent stores dx + a (.) x, a = the alpha
+// of the one 3x3x3 layer that reads it, so that layer runs two products instead of three; the tensor's other readers
+// (skips, down-sampling) fold a into their tangent weights.  Tensors read only by general kernels keep a = 0.
+static int wire_gauge(nbe_ctx* c) {
+    const int m = c->mid;
+    for (auto& kv : c->layers) {
+        Layer& L = kv.second;
+        const size_t na = (size_t)roundup(L.cin, 16) + 64, nb = (size_t)L.pw.ctiles * 32 * L.pw.ni + 64;
+        HIPCHK(hipMalloc((void**)&L.alpha, na * 4)); HIPCHK(hipMemset(L.alpha, 0, na * 4));
+        HIPCHK(hipMalloc((void**)&L.beta, nb * 4)); HIPCHK(hipMemset(L.beta, 0, nb * 4));
+    }
+    if (!c->gauge_flag) HIPCHK(hipMalloc((void**)&c->gauge_flag, 4));
+    auto lay = [&](const char* b, const char* l) -> Layer* {
+        auto it = c->layers.find(std::string(b) + "/" + l);
+        return it == c->layers.end() ? nullptr : &it->second;
+    };
+    // output of `producer` is read by the 3x3x3 layer `consumer`/conv_0 as its input channels [off, off + cout)
+    struct Rule { const char* pb; const char* pl; const char* consumer; int off; };
+    const Rule rules[] = {
+        {"conv_l00", "conv_1", "conv_l01", 0}, {"conv_l01", "conv_1", "conv_r00", 0}, {"down_l0", "conv_0", "conv_l1", 0},
+        {"conv_l1", "conv_1", "conv_r1", 0},   {"down_l1", "conv_0", "conv_l2", 0},   {"conv_l2", "conv_1", "conv_r2", 0},
+        {"down_l2", "conv_0", "conv_c", 0},    {"up_r2", "conv_0", "conv_r2", m},     {"up_r1", "conv_0", "conv_r1", m},
+        {"up_r0", "conv_0", "conv_r00", m},    {"conv_r00", "conv_1", "conv_r01", 0},
+    };
+    for (const Rule& r : rules) {
+        Layer *P = lay(r.pb, r.pl), *C = lay(r.consumer, "conv_0");
+        if (!P || !C || r.off + P->cout > C->cin) return fail("internal: gauge wiring %s/%s -> %s", r.pb, r.pl, r.consumer);
+        P->gout = C->alpha + r.off;
+    }
+    for (const char* b : kBlocks) {
+        if (!strncmp(b, "down_", 5) || !strncmp(b, "up_", 3)) continue;
+        Layer *L0 = lay(b, "conv_0"), *L1 = lay(b, "conv_1"), *Ls = lay(b, "skip");
+        L0->gout = L1->alpha;                                    // the hidden tensor is read by conv_1 only
+        L1->g6 = true;
+        if (strcmp(b, "conv_l00")) { L0->g6 = true; Ls->a_in = L0->alpha; }   // conv_l00 reads the input field: no tangent
+    }
+    lay("down_l0", "conv_0")->a_in = lay("conv_r00", "conv_0")->alpha;    // they read conv_l01 / conv_l1 / conv_l2's output
+    lay("down_l1", "conv_0")->a_in = lay("conv_r1", "conv_0")->alpha;
+    lay("down_l2", "conv_0")->a_in = lay("conv_r2", "conv_0")->alpha;
+    c->gauge = true;
+    return 0;
+}
 
 static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool style) {
     HIPCHK(hipSetDevice(c->device));
@@ -793,6 +849,8 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_weights = true; c->style = style; c->modulated = !style;
     c->mod_Om = NAN; c->mod_Dz = NAN;
+    const char* ge = getenv("NBE_GAUGE");
+    if (style && c->vel && c->prec == PREC_F16X3 && !(ge && atoi(ge) == 0)) return wire_gauge(c);
     return 0;
 }
 
@@ -832,7 +890,7 @@ int nbe_destroy(nbe_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     free_layers(c);
-    (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out);
+    (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -890,13 +948,26 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
     HIPCHK(hipSetDevice(c->device));
     // s = ((Om - 0.3) * 5, Dz - 1) in float32 (core :126-128)
     const float s0 = (Om - 0.3f) * 5.0f, s1 = Dz - 1.0f;
+    bool use_gauge = c->gauge;
+    if (use_gauge) {
+        // alpha of every layer first (the tangent weights of the general layers need their neighbours'); a style
+        // factor that is zero at this cosmology has no alpha: fall back to the three-product kernels for this call
+        HIPCHK(hipMemsetAsync(c->gauge_flag, 0, 4, c->stream));
+        for (auto& kv : c->layers)
+            launch_style_alpha(kv.second.sw, kv.second.sb, kv.second.cin, s0, s1, kv.second.alpha, c->gauge_flag, c->stream);
+        int bad = 0;
+        HIPCHK(hipMemcpyAsync(&bad, c->gauge_flag, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        use_gauge = bad == 0;
+    }
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         launch_modulate(L.weight, L.sw, L.sb, L.cout, L.cin, L.k * L.k * L.k, s0, s1, c->eps, L.first ? 1 : 0,
-                        L.wn, c->vel ? L.dwn : nullptr, c->stream);
+                        L.wn, c->vel ? L.dwn : nullptr, c->stream, use_gauge ? L.a_in : nullptr, use_gauge ? L.beta : nullptr);
         launch_pack(L.wn, L.cout, L.cin, L.kind, L.pw, L.pw.w, c->stream);
-        if (c->vel) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pw, L.pw.dw, c->stream);
+        if (c->vel && !(use_gauge && L.g6)) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pw, L.pw.dw, c->stream);
     }
+    c->gauge_active = use_gauge;
     HIPCHK(hipGetLastError());
     c->modulated = true; c->mod_Om = Om; c->mod_Dz = Dz;
     return 0;

@@ -68,6 +68,8 @@ struct ConvLaunch {
     Planes res;              // residual (same geometry as out), used when flags & F_RES
     int flags = 0;
     int set = 0;             // weight set (parity) index
+    const float* gout = nullptr;   // tangent gauge of the output (per cout), f16x3 kernels only
+    const float* beta = nullptr;   // gauged input: two-product tangent with this per-cout factor (3x3x3 f16x3 only)
 };
 
 void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, hipStream_t s);
@@ -76,7 +78,11 @@ void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, 
 // (w_n, dw_tot) in OIDHW from raw style parameters (style_layers_vel.py:62-105)
 void launch_modulate(const float* weight, const float* style_weight, const float* style_bias,
                      int cout, int cin, int k3, float s0, float s1, float eps, int first_layer,
-                     float* w_n, float* dw_tot /*nullable*/, hipStream_t s);
+                     float* w_n, float* dw_tot /*nullable*/, hipStream_t s,
+                     const float* a_in = nullptr, float* beta_out = nullptr);
+// alpha[ci] = (ds/dDz) / s of the style modulation of a layer; *flag |= 1 where s is (numerically) zero
+void launch_style_alpha(const float* style_weight, const float* style_bias, int cin, float s0, float s1,
+                        float* alpha, int* flag, hipStream_t s);
 // OIDHW -> packed layout; `kind`: 0 conv3, 1 skip(1x1x1), 2 down(k2 s2), 3 up(k2, 8 parity sets)
 void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s);
 

@@ -235,6 +235,7 @@ void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, 
     ka.nchunk = pw.cin_pad / prec_ck(pw.prec, pw.mode);
     ka.cout_groups = prec_is_half(pw.prec) ? (pw.cout + 7) / 8 : (pw.cout + 3) / 4;
     ka.flags = L.flags;
+    ka.gout = L.gout; ka.beta = L.beta;
     ka.ntiles = (int)((ka.Q + TILE_VOX - 1) / TILE_VOX);
     if (prec_is_half(pw.prec)) { launch_conv_h3(pw, ka, vel, has_dx, s); return; }
     const int ct = pw.ctiles;
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
                                                        const float* __restrict__ sb,
                                                        int cin, int k3, float s0, float s1, float eps,
                                                        int first_layer, float* __restrict__ w_n,
-                                                       float* __restrict__ dw_tot) {
+                                                       float* __restrict__ dw_tot, const float* __restrict__ a_in,
+                                                       float* __restrict__ beta_out) {
     __shared__ double scratch[4];
     const int co = blockIdx.x;
     const int n = cin * k3;
@@ -295,6 +297,8 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
     const float norm = sqrtf((float)sww + eps);
     const float dnorm = -(float)swd / (norm * norm * norm);
     const float inv_dz = 1.0f / (s1 + 1.0f);
+    // dw_tot[co, ci, :] = w_n[co, ci, :] * (alpha[ci] + beta[co]) with alpha = ds/s (launch_style_alpha)
+    if (beta_out && threadIdx.x == 0) beta_out[co] = dnorm * norm;
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const int ci = e / k3;
         const float smod = sw[2 * ci] * s0 + sw[2 * ci + 1] * s1 + sb[ci];
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
         if (dw_tot) {
             float d = dws / norm + w * dnorm;
             if (first_layer) d += wn * inv_dz;
+            if (a_in) d -= wn * a_in[ci];                        // the input's tangent is stored as dx + a_in * x
             dw_tot[(size_t)co * n + e] = d;
         }
     }
@@ -312,9 +317,26 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
 
 void launch_modulate(const float* weight, const float* style_weight, const float* style_bias,
                      int cout, int cin, int k3, float s0, float s1, float eps, int first_layer,
-                     float* w_n, float* dw_tot, hipStream_t s) {
+                     float* w_n, float* dw_tot, hipStream_t s, const float* a_in, float* beta_out) {
     hipLaunchKernelGGL(modulate_kernel, dim3(cout), dim3(256), 0, s, weight, style_weight, style_bias,
-                       cin, k3, s0, s1, eps, first_layer, w_n, dw_tot);
+                       cin, k3, s0, s1, eps, first_layer, w_n, dw_tot, a_in, beta_out);
+}
+
+__global__ void style_alpha_kernel(const float* __restrict__ sw, const float* __restrict__ sb, int cin, float s0,
+                                   float s1, float* __restrict__ alpha, int* __restrict__ flag) {
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= cin) return;
+    const float smod = sw[2 * ci] * s0 + sw[2 * ci + 1] * s1 + sb[ci];
+    const float al = sw[2 * ci + 1] / smod;
+    const bool ok = fabsf(smod) > 1e-20f && isfinite(al);
+    alpha[ci] = ok ? al : 0.f;
+    if (!ok) atomicOr(flag, 1);
+}
+
+void launch_style_alpha(const float* style_weight, const float* style_bias, int cin, float s0, float s1,
+                        float* alpha, int* flag, hipStream_t s) {
+    hipLaunchKernelGGL(style_alpha_kernel, dim3((cin + 63) / 64), dim3(64), 0, s, style_weight, style_bias, cin, s0, s1,
+                       alpha, flag);
 }
 
 // packed layout: [set][ct][stage = chunk*nseg + seg][tap][gl][co][e]; channel = chunk*CK + gl*4 + e

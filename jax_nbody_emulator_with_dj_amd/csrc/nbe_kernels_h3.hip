@@ -16,6 +16,7 @@
 
 #include "nbe_kernels_internal.h"
 #include <cstdlib>
+#include <cstdio>
 #include <algorithm>
 
 #ifndef NBE_DBG
@@ -57,13 +58,15 @@ __device__ __forceinline__ void h3_store2(const ConvKArgs& a, int ct, int it, in
     const bool act = a.flags & F_ACT, res = a.flags & F_RES;
     int unit[4];
     bool uok[4];
-    f32x4 bv[4];
+    f32x4 bv[4], gv[4];
+    const bool gauge = VEL && a.gout;                            // stored tangent = dy + gout[o] * y (see conv_h3g_kernel)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         unit[k] = ct * 8 + 4 * it + k;                           // 8-channel group of the output
         uok[k] = unit[k] < a.cout_groups;
         if (!uok[k]) unit[k] = a.cout_groups - 1;
         bv[k] = *(const f32x4*)(a.bias + unit[k] * 8 + 4 * lh);
+        if (gauge) gv[k] = *(const f32x4*)(a.gout + unit[k] * 8 + 4 * lh);
     }
     half4 rh[8], rl[8], dh[8], dl[8];
     if (res) {
@@ -106,6 +109,10 @@ __device__ __forceinline__ void h3_store2(const ConvKArgs& a, int ct, int it, in
                 if (VEL) dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
                 v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
             }
+        }
+        if (gauge) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[e] += gv[k][e] * v[e];
         }
         if (uok[k] && ok[jt]) {
             const long ob = ((long)(a.out_g0 + PARTS * unit[k]) * a.out_pstride + o[jt]) * 16 + 8 * lh;
@@ -1001,6 +1008,258 @@ static void launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The gauged-tangent kernel: two float32 products per tap instead of three (f16x3, velocity, style modulation)
+// ------------------------------------------------------------------------------------------------
+// A style-modulated weight is w_n[o,i,k] = w[o,i,k] s[i] / norm[o] (style_layers_vel.py:62-105), so its derivative
+// along Dz factorises: dw[o,i,k] = w_n[o,i,k] * (alpha[i] + beta[o]), alpha = s'/s, beta = norm' ... (modulate_kernel).
+// Hence
+//     dy = W.dx + dW.x = W.(dx + alpha (.) x) + beta (.) (W.x):
+// if the PRODUCER of x stores the tangent as dx~ = dx + alpha (.) x (its epilogue knows alpha as `gout`, one FMA per
+// element), this layer needs W.x and W.dx~ only -- six f16 MFMAs per tile and tap pair where conv_h3q_kernel issues
+// nine, no dW operand at all, and beta[o] * (W.x) is one FMA per output in the epilogue.  The engine assigns every
+// tensor the gauge of its one 3x3x3 consumer; its other consumers (1x1x1 skips, down-sampling) keep the general
+// kernels with dW - W (.) alpha as their tangent weight (launch_modulate a_in), which is the same identity.
+//
+// Without dW a whole (chunk, dz) group of weights is 36 KB: weights AND patches are double-buffered by group
+// (2 x 36 KB + 2 x 44 KB = the same 160 KB), every DMA is issued a full group (~2 us) ahead of its use, and a group
+// ends with ONE barrier.  Operand layout, tap pairing, MFMA shape and the wave tile are those of conv_h3q_kernel.
+constexpr int HG_WG = 9 * HQ_TAPU;                         // units of one group's weights (set w)
+static_assert(2 * HG_WG == HQ_XBASE, "the two weight buffers fill exactly what conv_h3q_kernel uses for four");
+
+__global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
+    f32x4* lds = lds_h3;
+    const half8* L8 = (const half8*)lds_h3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
+    const int it = wave & 1, jq = wave >> 1;
+
+    const int tile = xcd_tile(blockIdx.x, a.ntiles);             // z fastest, as in conv_h3q_kernel
+    const int ct = blockIdx.y;
+    const int z = tile % a.Dv, tyx = tile / a.Dv;
+    const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
+    const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS;
+    const int ngroups = 3 * a.nchunk;
+
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // ---- DMA of group g into buffers g & 1: 36 wave-instructions of weights (5 slots per wave), 24 + 24 of the
+    // x and dx~ patches (3 + 3 slots per wave)
+    const long wct = (long)ct * ngroups * HG_WG;
+    auto dma_w = [&](int g, int t) {
+        const int n = wave + 8 * t;
+        if (n >= HG_WG / 64) return;
+        dma16s((const char*)a.w + (wct + (long)g * HG_WG + n * 64) * 16, lane16, lds + (g & 1) * HG_WG + n * 64);
+    };
+    unsigned xoff[3];
+    bool xval[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = (wave + 8 * t) % 6;
+        const int u = k * 64 + lane;
+        xval[t] = u < HP_PL;
+        const int uu = xval[t] ? u : HP_PL - 1;
+        const int row = uu / HP_RS, col = uu - row * HP_RS;
+        xoff[t] = (unsigned)(row * a.W + col) * 16u;
+    }
+    auto patch_offset = [&](int g) -> long {                     // g = chunk*3 + dz
+        const int chunk = g / 3, dz = g - chunk * 3;
+        return ((long)chunk * 4 * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
+    };
+    auto dma_x = [&](int tensor, int t, long xo, int buf) {
+        const int n = wave + 8 * t, pl = n / 6, k = n - 6 * pl;
+        if (xval[t])
+            dma16s((const char*)(tensor ? a.dx : a.x) + xo + (long)pl * a.in_pstride * 16, xoff[t],
+                   lds + HQ_XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HQ_PP + k * 64);
+    };
+    auto dma_slot = [&](int k, int g, long xo) {                 // slot k of the 11 of group g
+        if (k < 5) dma_w(g, k);
+        else if (k < 8) dma_x(0, k - 5, xo, g & 1);
+        else if (k < 11) dma_x(1, k - 8, xo, g & 1);
+    };
+
+    f32x4 ym[8], yc[8], dm[8], dc[8];                            // AGPRs, updated in place (see conv_h3q_kernel)
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ym[t][e] = 0.f; yc[t][e] = 0.f; dm[t][e] = 0.f; dc[t][e] = 0.f; }
+    auto mm = [&](f32x4& acc, const half8& A, const half8& B) {
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+    };
+
+    const int aP = (ks * 4 + 2 * kh) * 64 + 32 * it + c;
+    const int bB = (2 * kh) * HQ_PP + (2 * jq) * HP_RS + c;
+    const int bP1 = bB + ks, bP32 = bB + 32 * ks;
+    auto LA = [&](half8 (&r)[2], int idx) {
+        r[0] = L8[idx];
+        r[1] = L8[idx + 16];
+    };
+    auto LB = [&](half8 (&r)[4], int idx) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) r[nt] = L8[idx + (nt >> 1) * HP_RS + 16 * (nt & 1)];
+    };
+    // one product on the wave tile: 8 MFMAs; slot >= 0: DMA slots `slot`, `slot + 1` of group gn after the 4th / 8th
+    auto MM8 = [&](f32x4 (&acc)[8], const half8 (&A)[2], const half8 (&B)[4], int slot, int gn, long xo, bool px) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            mm(acc[t], A[t >> 2], B[t & 3]);
+            if (slot >= 0 && (t & 3) == 3) {
+                if (px) dma_slot(slot + (t >> 2), gn, xo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#define NBE_SB __builtin_amdgcn_sched_barrier(0)
+    half8 wh[2], wl[2], xh[4], xl[4], dxh[4], dxl[4];
+    // A tap pair: six products.  On entry wh, xl and xh of the pair are loaded (or in flight); preXl / preW / preXh
+    // request those of whatever follows as soon as the registers are free.  Dependent MFMAs are >= 8 MFMAs apart.
+    auto pair = [&](int slot0, int gn, long xo, bool px, int wa, int xp, auto&& preXl, auto&& preW, auto&& preXh) {
+        LA(wl, wa + 64 + aP); LB(dxh, xp + HQ_XT);
+        NBE_SB; MM8(yc, wh, xl, slot0, gn, xo, px); NBE_SB;
+        LB(dxl, xp + HQ_XT + HQ_PP);
+        NBE_SB; MM8(ym, wh, xh, slot0 < 0 ? -1 : slot0 + 2, gn, xo, px); NBE_SB;
+        MM8(dm, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, gn, xo, px); NBE_SB;
+        preXl();
+        NBE_SB; MM8(dc, wh, dxl, slot0 < 0 ? -1 : slot0 + 6, gn, xo, px); NBE_SB;
+        preW();
+        NBE_SB; MM8(yc, wl, xh, slot0 < 0 ? -1 : slot0 + 8, gn, xo, px); NBE_SB;
+        preXh();
+        NBE_SB; MM8(dc, wl, dxh, slot0 < 0 ? -1 : slot0 + 10, gn, xo, px); NBE_SB;
+    };
+
+    // ---- prologue: group 0
+    {
+        const long x0off = patch_offset(0);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) dma_slot(k, 0, x0off);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
+    for (int g = 0; g < ngroups; ++g) {
+        const bool px = g + 1 < ngroups;
+        const long xo = px ? patch_offset(g + 1) : 0;
+        const int wb = (g & 1) * HG_WG, xb = HQ_XBASE + (g & 1) * HQ_XB;
+        half8 a1w[2], a0[2], b1x[4], b1d[4];
+        // single tap 4 = (dy 1, dx 1): the lane-group halves select the PART: [wh|wl].[xl|xh] and [0|wh].[xl|xh]
+        const int aS1 = wb + 4 * HQ_TAPU + (2 * kh + ks) * 64 + 32 * it + c;
+        const int aS0 = wb + 4 * HQ_TAPU + (2 * kh) * 64 + 32 * it + c;
+        const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + (2 * jq) * HP_RS + c + SH4;
+
+        LA(wh, wb + aP); LB(xl, xb + bP1 + HQ_PP); LB(xh, xb + bP1);
+        pair(0, g + 1, xo, px, wb, xb + bP1,                                           // taps (0,1) + the DMA of group g+1
+             [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * HQ_TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); });
+        pair(-1, g + 1, xo, px, wb + 2 * HQ_TAPU, xb + 2 + bP32,                        // taps (2,3)
+             [&] { LB(b1x, bS1); }, [&] { LA(a1w, aS1); LA(a0, aS0); }, [&] { LB(b1d, bS1 + HQ_XT); });
+        {
+            const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            a0[0] = ks ? a0[0] : zero;                                   // [0 | wh]
+            a0[1] = ks ? a0[1] : zero;
+        }
+        NBE_SB; MM8(yc, a1w, b1x, -1, 0, 0, false); NBE_SB;                  // wh.xl + wl.xh
+        LB(xl, xb + SH5 + bP32 + HQ_PP);
+        NBE_SB; MM8(ym, a0, b1x, -1, 0, 0, false); NBE_SB;                   // wh.xh
+        LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * HQ_TAPU + aP);
+        NBE_SB; MM8(dc, a1w, b1d, -1, 0, 0, false); NBE_SB;                  // wh.dxl + wl.dxh
+        MM8(dm, a0, b1d, -1, 0, 0, false); NBE_SB;                           // wh.dxh
+        pair(-1, g + 1, xo, px, wb + 5 * HQ_TAPU, xb + SH5 + bP32,                      // taps (5,6)
+             [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * HQ_TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); });
+        pair(-1, g + 1, xo, px, wb + 7 * HQ_TAPU, xb + SH7 + bP1, [&] {}, [&] {}, [&] {});    // taps (7,8)
+        // everything of group g+1 has landed, and every wave is done with the buffers of group g
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+    }
+#undef NBE_SB
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
+
+    // ---- epilogue (layout and load-first order of conv_h3q_kernel): y = W.x + b, dy = W.dx~ + beta * (W.x)
+    {
+        const bool act = a.flags & F_ACT, res = a.flags & F_RES, gauge = a.gout != nullptr;
+        int unit[2];
+        bool uok[2];
+        f32x4 bv[2], be[2], gv[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            unit[mt] = ct * 8 + 4 * it + 2 * mt + ks;
+            uok[mt] = unit[mt] < a.cout_groups;
+            if (!uok[mt]) unit[mt] = a.cout_groups - 1;
+            bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
+            be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
+            if (gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
+        }
+        long o[4];
+        bool ook[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int yy = y0 + 2 * jq + (nt >> 1), xx = x0 + 16 * (nt & 1) + c;
+            ook[nt] = yy < a.Hv && xx < a.Wv;
+            o[nt] = ook[nt] ? ((long)z * a.Ho + yy) * a.Wo + xx : (long)z * a.Ho * a.Wo;
+        }
+        half4 rh[8], rl[8], dh[8], dl[8];
+        if (res) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const long rb = ((long)(2 * unit[t >> 2]) * a.res_pstride + o[t & 3]) * 16 + 8 * kh;
+                const long rl_ = rb + a.res_pstride * 16;
+                rh[t] = *(const half4*)((const char*)a.r + rb);
+                rl[t] = *(const half4*)((const char*)a.r + rl_);
+                dh[t] = *(const half4*)((const char*)a.dr + rb);
+                dl[t] = *(const half4*)((const char*)a.dr + rl_);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int mt = t >> 2, nt = t & 3;
+            f32x4 v, dv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float yp = ym[t][e] + yc[t][e] * H3_INV;
+                v[e] = yp + bv[mt][e];
+                dv[e] = dm[t][e] + dc[t][e] * H3_INV + be[mt][e] * yp;
+            }
+            if (res) { v += join4(rh[t], rl[t]); dv += join4(dh[t], dl[t]); }
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                    v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                }
+            }
+            if (gauge) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
+            }
+            if (uok[mt] && ook[nt]) {
+                const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + o[nt]) * 16 + 8 * kh;
+                const long ol = ob + a.out_pstride * 16;
+                half4 hi, lo;
+                split4(v, hi, lo);
+                *(half4*)((char*)a.y + ob) = hi;
+                *(half4*)((char*)a.y + ol) = lo;
+                split4(dv, hi, lo);
+                *(half4*)((char*)a.dy + ob) = hi;
+                *(half4*)((char*)a.dy + ol) = lo;
+            }
+        }
+    }
+}
+
+static void launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
+    constexpr size_t smem = (size_t)HQ_LDS_UNITS * 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_h3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
+    ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
+    ka.ntiles = ka.Dv * ka.tny * ka.tnx;
+    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    hipLaunchKernelGGL(conv_h3g_kernel, grid, block, smem, s, ka);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The two-accumulator variants on the 16x16x32 shape: f16x3 without velocity and plain f16 with velocity
 // ------------------------------------------------------------------------------------------------
 // Both have one product for the first accumulator set and two for the second:
@@ -1339,6 +1598,14 @@ void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_d
     if (vel) { if (has_dx) F<__VA_ARGS__, true, true>(ka, ct, s); else F<__VA_ARGS__, true, false>(ka, ct, s); } \
     else F<__VA_ARGS__, false, false>(ka, ct, s);
     static const bool shape32 = getenv("NBE_H3_SHAPE") && atoi(getenv("NBE_H3_SHAPE")) == 32;   // A/B: 32x32x16 MFMAs
+    if (ka.beta) {                                               // gauged input tangent: only conv_h3g_kernel reads it
+        if (!(pw.mode == MODE_FLAT3 && split && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) {
+            fprintf(stderr, "nbe: internal error: gauged tangent passed to a layer without a gauged kernel\n");
+            abort();
+        }
+        launch_h3g(ka, ct, s);
+        return;
+    }
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
         if (split && vel && has_dx && !shape32 && sched == 0) { launch_h3q(ka, ct, s); return; }
         if (split && !vel && !shape32) { launch_h2q<true>(ka, ct, s); return; }

@@ -23,6 +23,9 @@ struct ConvKArgs {
     const float* bias; const float* w; const float* dw;
     int nchunk; int cout_groups; int flags; int ntiles;
     int tny, tnx;            // patch kernel: number of 8-row / 32-column tiles per output plane
+    // tangent gauge (f16x3 style path, see conv_h3g_kernel): per-cout vectors, either may be NULL
+    const float* gout;       // the stored tangent is dy + gout[o] * y
+    const float* beta;       // the input tangent is in this layer's gauge: dy = W.dx~ + beta[o] * (W.x), no dW
 };
 
 __device__ __forceinline__ void dma16(const float* src, f32x4* dst_wave_base) {
