@@ -20,6 +20,8 @@
 // The tangent (velocity) path shares every staged operand: y += W.X, dy += dW.X + W.dX.
 
 #include "nbe_kernels_internal.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace nbe {
 
@@ -28,7 +30,9 @@ namespace nbe {
 
 extern __shared__ __attribute__((aligned(16))) f32x4 lds_dyn[];
 
-template <int MODE, bool VEL, bool HAS_DX, int NI>
+// G6 (3x3x3 with input tangent only): the input tangent arrives in this layer's gauge, dy = W.dx~ + beta * (W.x) --
+// no dW operand and two products per tap instead of three (see conv_h3g_kernel in nbe_kernels_h3.hip).
+template <int MODE, bool VEL, bool HAS_DX, int NI, bool G6 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int CK = mode_ck(MODE), GL = CK / 4, TAPS = mode_taps(MODE);
     constexpr int COUT_T = 32 * NI;
@@ -36,10 +40,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
     constexpr int WP = TAPS * GL * COUT_T;           // 16-byte pieces of one weight stage
     constexpr int XP = GL * XV;                      // 16-byte pieces of one activation stage
     constexpr bool DX = VEL && HAS_DX;
-    constexpr int OFF_W = 0, OFF_DW = WP, OFF_X = OFF_DW + (VEL ? WP : 0), OFF_DXX = OFF_X + XP;
+    constexpr bool DWT = VEL && !G6;                 // a tangent weight operand exists
+    static_assert(!G6 || (DX && MODE == MODE_FLAT3), "gauged form: 3x3x3 layers with an input tangent");
+    constexpr int OFF_W = 0, OFF_DW = WP, OFF_X = OFF_DW + (DWT ? WP : 0), OFF_DXX = OFF_X + XP;
     constexpr int BUF = OFF_DXX + (DX ? XP : 0);
     constexpr int NIW = WP / 64, NIX = XP / 64;
-    constexpr int NW_TOT = NIW * (VEL ? 2 : 1);
+    constexpr int NW_TOT = NIW * (DWT ? 2 : 1);
     constexpr int NINSTR = NW_TOT + NIX * (DX ? 2 : 1);
     static_assert(WP % 64 == 0 && XP % 64 == 0, "stage arrays must be whole wave-instructions");
 
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
             const int n = wave + 4 * t;              // wave-uniform instruction slot
             if (n < NIW) {
                 dma16(a.w + wbase + (long)(n * 64 + lane) * 4, buf + OFF_W + n * 64);
-            } else if (VEL && n < NW_TOT) {
+            } else if (DWT && n < NW_TOT) {
                 const int m = n - NIW;
                 dma16(a.dw + wbase + (long)(m * 64 + lane) * 4, buf + OFF_DW + m * 64);
             } else if (n < NINSTR) {
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
                 for (int it = 0; it < NI; ++it) {
                     const int o = (tap * GL + 2 * kg + lh) * COUT_T + 32 * it + li;
                     wv[it] = buf[OFF_W + o];
-                    if (VEL) dwv[it] = buf[OFF_DW + o];
+                    if (DWT) dwv[it] = buf[OFF_DW + o];
                 }
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
 #pragma unroll
                         for (int jt = 0; jt < 2; ++jt) {
                             accy[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[it][r], xv[jt][r], accy[it][jt], 0, 0, 0);
-                            if (VEL) accd[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dwv[it][r], xv[jt][r], accd[it][jt], 0, 0, 0);
+                            if (DWT) accd[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dwv[it][r], xv[jt][r], accd[it][jt], 0, 0, 0);
                             if (DX) accd[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[it][r], dxv[jt][r], accd[it][jt], 0, 0, 0);
                         }
                     }
@@ -181,6 +187,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
                 f32x4 v, dv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = accy[it][jt][4 * k + e] + bv[e]; dv[e] = accd[it][jt][4 * k + e]; }
+                if (G6) {
+                    const f32x4 be = *(const f32x4*)(a.beta + cg * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += be[e] * accy[it][jt][4 * k + e];
+                }
                 if (res) {
                     const long ro = ((long)cg * a.res_pstride + o) * 4;
                     const f32x4 rv = *(const f32x4*)(a.r + ro);
@@ -194,6 +205,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
                         v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
                     }
                 }
+                if (VEL && a.gout) {                                  // the stored tangent is dy + gout * y
+                    const f32x4 gv = *(const f32x4*)(a.gout + cg * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += gv[e] * v[e];
+                }
                 const long oo = ((long)(a.out_g0 + cg) * a.out_pstride + o) * 4;
                 *(f32x4*)(a.y + oo) = v;
                 if (VEL) *(f32x4*)(a.dy + oo) = dv;
@@ -202,14 +218,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKArgs a) {
     }
 }
 
-template <int MODE, bool VEL, bool HAS_DX, int NI>
+template <int MODE, bool VEL, bool HAS_DX, int NI, bool G6 = false>
 static void launch_conv_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
     constexpr int CK = mode_ck(MODE), GL = CK / 4, TAPS = mode_taps(MODE);
     constexpr int XV = (MODE == MODE_FLAT3) ? 320 : 256;
     constexpr int WP = TAPS * GL * 32 * NI, XP = GL * XV;
-    constexpr int BUF = WP * (VEL ? 2 : 1) + XP * ((VEL && HAS_DX) ? 2 : 1);
+    constexpr int BUF = WP * ((VEL && !G6) ? 2 : 1) + XP * ((VEL && HAS_DX) ? 2 : 1);
     constexpr size_t smem = (size_t)2 * BUF * 16 + 256 * sizeof(int);
-    auto kern = conv_mfma_kernel<MODE, VEL, HAS_DX, NI>;
+    auto kern = conv_mfma_kernel<MODE, VEL, HAS_DX, NI, G6>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -239,6 +255,15 @@ void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, 
     ka.ntiles = (int)((ka.Q + TILE_VOX - 1) / TILE_VOX);
     if (prec_is_half(pw.prec)) { launch_conv_h3(pw, ka, vel, has_dx, s); return; }
     const int ct = pw.ctiles;
+    if (ka.beta) {                                               // gauged input tangent: 3x3x3 layers only
+        if (!(pw.mode == MODE_FLAT3 && vel && has_dx)) {
+            fprintf(stderr, "nbe: internal error: gauged tangent passed to a layer without a gauged kernel\n");
+            abort();
+        }
+        if (pw.ni == 2) launch_conv_t<MODE_FLAT3, true, true, 2, true>(ka, ct, s);
+        else launch_conv_t<MODE_FLAT3, true, true, 1, true>(ka, ct, s);
+        return;
+    }
 #define NBE_DISPATCH(MODE)                                                                   \
     if (vel) {                                                                               \
         if (has_dx) { if (pw.ni == 2) launch_conv_t<MODE, true, true, 2>(ka, ct, s);        \

@@ -1027,6 +1027,12 @@ constexpr int HG_WG = 9 * HQ_TAPU;                         // units of one group
 static_assert(2 * HG_WG == HQ_XBASE, "the two weight buffers fill exactly what conv_h3q_kernel uses for four");
 
 __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
+#if NBE_DBG   // phases as h3q_stamps: 0 prologue, 1 group up to its barrier, 2 own DMA, 3 barrier, 4 the three products after it, 7 epilogue
+    unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NBE_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[i] += t_ - tk0; tk0 = t_; }
+#else
+#define NBE_STAMP(i)
+#endif
     f32x4* lds = lds_h3;
     const half8* L8 = (const half8*)lds_h3;
     const int tid = threadIdx.x;
@@ -1113,12 +1119,15 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     half8 wh[2], wl[2], xh[4], xl[4], dxh[4], dxl[4];
     // A tap pair: six products.  On entry wh, xl and xh of the pair are loaded (or in flight); preXl / preW / preXh
     // request those of whatever follows as soon as the registers are free.  Dependent MFMAs are >= 8 MFMAs apart.
-    auto pair = [&](int slot0, int gn, long xo, bool px, int wa, int xp, auto&& preXl, auto&& preW, auto&& preXh) {
+    // (mid: after the third product every LDS read of the pair has been issued -- the group's barrier goes there)
+    auto pair = [&](int slot0, int gn, long xo, bool px, int wa, int xp, auto&& preXl, auto&& preW, auto&& preXh,
+                    auto&& mid) {
         LA(wl, wa + 64 + aP); LB(dxh, xp + HQ_XT);
         NBE_SB; MM8(yc, wh, xl, slot0, gn, xo, px); NBE_SB;
         LB(dxl, xp + HQ_XT + HQ_PP);
         NBE_SB; MM8(ym, wh, xh, slot0 < 0 ? -1 : slot0 + 2, gn, xo, px); NBE_SB;
         MM8(dm, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, gn, xo, px); NBE_SB;
+        mid();
         preXl();
         NBE_SB; MM8(dc, wh, dxl, slot0 < 0 ? -1 : slot0 + 6, gn, xo, px); NBE_SB;
         preW();
@@ -1134,6 +1143,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         for (int k = 0; k < 11; ++k) dma_slot(k, 0, x0off);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        NBE_STAMP(0)
+        LA(wh, aP); LB(xl, HQ_XBASE + bP1 + HQ_PP); LB(xh, HQ_XBASE + bP1);
     }
 
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
@@ -1141,17 +1152,18 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         const bool px = g + 1 < ngroups;
         const long xo = px ? patch_offset(g + 1) : 0;
         const int wb = (g & 1) * HG_WG, xb = HQ_XBASE + (g & 1) * HQ_XB;
+        const int wbn = HG_WG - wb, xbn = HQ_XBASE + ((g + 1) & 1) * HQ_XB;
         half8 a1w[2], a0[2], b1x[4], b1d[4];
         // single tap 4 = (dy 1, dx 1): the lane-group halves select the PART: [wh|wl].[xl|xh] and [0|wh].[xl|xh]
         const int aS1 = wb + 4 * HQ_TAPU + (2 * kh + ks) * 64 + 32 * it + c;
         const int aS0 = wb + 4 * HQ_TAPU + (2 * kh) * 64 + 32 * it + c;
         const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + (2 * jq) * HP_RS + c + SH4;
 
-        LA(wh, wb + aP); LB(xl, xb + bP1 + HQ_PP); LB(xh, xb + bP1);
         pair(0, g + 1, xo, px, wb, xb + bP1,                                           // taps (0,1) + the DMA of group g+1
-             [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * HQ_TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); });
+             [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * HQ_TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
+             [&] {});
         pair(-1, g + 1, xo, px, wb + 2 * HQ_TAPU, xb + 2 + bP32,                        // taps (2,3)
-             [&] { LB(b1x, bS1); }, [&] { LA(a1w, aS1); LA(a0, aS0); }, [&] { LB(b1d, bS1 + HQ_XT); });
+             [&] { LB(b1x, bS1); }, [&] { LA(a1w, aS1); LA(a0, aS0); }, [&] { LB(b1d, bS1 + HQ_XT); }, [&] {});
         {
             const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
             a0[0] = ks ? a0[0] : zero;                                   // [0 | wh]
@@ -1164,11 +1176,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         NBE_SB; MM8(dc, a1w, b1d, -1, 0, 0, false); NBE_SB;                  // wh.dxl + wl.dxh
         MM8(dm, a0, b1d, -1, 0, 0, false); NBE_SB;                           // wh.dxh
         pair(-1, g + 1, xo, px, wb + 5 * HQ_TAPU, xb + SH5 + bP32,                      // taps (5,6)
-             [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * HQ_TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); });
-        pair(-1, g + 1, xo, px, wb + 7 * HQ_TAPU, xb + SH7 + bP1, [&] {}, [&] {}, [&] {});    // taps (7,8)
-        // everything of group g+1 has landed, and every wave is done with the buffers of group g
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
+             [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * HQ_TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
+             [&] {});
+        // taps (7,8).  The group's one barrier sits after the third product: by then this wave has read everything it
+        // needs from the buffers of group g, and all of group g+1 has landed once every wave has waited for its own
+        // DMA -- the first operands of group g+1 are requested under the last three products.
+        pair(-1, g + 1, xo, px, wb + 7 * HQ_TAPU, xb + SH7 + bP1,
+             [&] { if (px) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (px) LA(wh, wbn + aP); }, [&] { if (px) LB(xh, xbn + bP1); },
+             [&] { NBE_STAMP(1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); NBE_STAMP(2)
+                   asm volatile("s_barrier" ::: "memory"); NBE_STAMP(3) });
+        NBE_STAMP(4)
     }
 #undef NBE_SB
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
@@ -1243,6 +1260,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
             }
         }
     }
+#if NBE_DBG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NBE_STAMP(7)
+    if (lane == 0 && (blockIdx.x & 63) == 0) {                   // a sample: the atomics of every wave would dominate the run
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&h3q_stamps[i], tk[i]);
+        atomicAdd(&h3q_stamps[8], 1ull);
+    }
+#endif
+#undef NBE_STAMP
 }
 
 static void launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {

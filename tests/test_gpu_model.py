@@ -71,6 +71,42 @@ def test_premod_vel_small(engine_factory, small, prec):
     _check(d, v, d_o, v_o, "premod-vel mid8")
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_gauged_tangent_paths(engine_factory, small, monkeypatch, prec):
+    """Style path with velocity: the two-product gauged tangent (default; conv_h3g_kernel / conv_mfma_kernel<G6>) against the
+    three-product general kernels (NBE_GAUGE=0), and the fall-back to those when a style factor is exactly zero
+    (alpha = s'/s does not exist then).  Same tolerances as everywhere: both forms are float32-equivalent."""
+    import copy
+    from oracle import model as M
+    p, x, d_o, v_o = small
+
+    def run(params):
+        e = engine_factory(mid_chan=8, compute_vel=True, precision=prec)
+        e.load_params(params, premodulated=False)
+        e.set_cosmology(OM, DZ)
+        e.profile_enable(True)
+        d, v = e.forward(x, DZ, VF)
+        e.profile_enable(False)
+        return d, v, any(k["kernel"].startswith(("conv_h3g", "conv_mfma_g")) for k in e.profile_read())
+
+    d1, v1, g1 = run(p)
+    monkeypatch.setenv("NBE_GAUGE", "0")
+    d0, v0, g0 = run(p)
+    monkeypatch.delenv("NBE_GAUGE")
+    assert g1 and not g0
+    _check(d1, v1, d_o, v_o, "gauged")
+    _check(d0, v0, d_o, v_o, "general")
+    assert rel_l2(d1, d0) <= 2e-6 and rel_l2(v1, v0) <= 5e-6
+
+    pz = copy.deepcopy(p)
+    pz["params"]["conv_l1"]["conv_1"]["style_weight"][3] = 0
+    pz["params"]["conv_l1"]["conv_1"]["style_bias"][3] = 0
+    dz_o, vz_o = M.forward(pz, x[None], OM, DZ, VF)
+    dz, vz, gz = run(pz)
+    assert not gz, "a zero style factor must switch the gauged kernels off"
+    _check(dz, vz, dz_o[0], vz_o[0], "zero style factor")
+
+
 def test_float16_mode(engine_factory, small):
     """The float16 engine ("f16": float16 operands and stored activations, float32 accumulation -- the
     arithmetic of the reference's dtype=float16 configuration) against the float64 oracle.  Every one of the
