@@ -185,7 +185,11 @@ def main():
         # the committed rocprofv3 --pmc passes of this exact workload (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # see the file named beside each value) and are reported only when the configuration matches.
         traffic = None
-        if (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
+        gauged = dom["kernel"].startswith("conv_h3g<FLAT3,vel,dx")   # two-product tangent (default on the style path)
+        if (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and gauged:
+            if plan.startswith("(1, 1, 1)") and os.environ.get("NBE_PERIODIC", "1") != "0":
+                traffic = 58.3e9            # profiles/r01_pmc_fetch_write_default_gauged.txt
+        elif (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
             if plan.startswith("(1, 1, 1)") and os.environ.get("NBE_PERIODIC", "1") != "0":
                 traffic = 59.6e9            # profiles/r01_pmc_fetch_write_default_periodic.txt
             elif plan.startswith("(1, 1, 1)"):

@@ -79,7 +79,11 @@ int nbe_load_premod_weights(nbe_ctx* ctx, const nbe_layer_desc* layers, int nlay
 
 /* Style cores: (Om, Dz) -> style vector s = ((Om-0.3)*5, Dz-1) and the per-layer weight modulation,
  * demodulation and d/dDz (style_nbody_emulator_vel_core.py:126-128, style_layers_vel.py:62-105).
- * Runs the modulate + pack kernels.  No-op for premodulated weights. */
+ * Runs the modulate + pack kernels.  No-op for premodulated weights.
+ * With velocity (f32 / f16x3) the tangent of style_layers_vel.py:98-105, dy = W.dx + dW.x, is evaluated as
+ * W.(dx + alpha x) + beta (W.x) using dW = W (.) (alpha[cin] + beta[cout]) of the style modulation (two contractions
+ * per 3x3x3 layer instead of three; same result within rounding).  env NBE_GAUGE=0 at load time keeps the
+ * three-product form; a style factor that is exactly zero at (Om, Dz) selects it for that cosmology. */
 int nbe_set_cosmology(nbe_ctx* ctx, float Om, float Dz);
 
 /* model.apply(params, x[None], Om, Dz, vel_fac) for ONE batch element

@@ -75,7 +75,7 @@ struct Layer {
     float *weight = nullptr, *sw = nullptr, *sb = nullptr;   // raw style parameters (device)
     float *wn = nullptr, *dwn = nullptr;          // modulated OIDHW (device)
     PackedW pw;
-    // tangent gauge (f16x3 style path, see conv_h3g_kernel): dw = w_n (.) (alpha[ci] + beta[co])
+    // tangent gauge (style path, see conv_h3g_kernel): dw = w_n (.) (alpha[ci] + beta[co])
     float *alpha = nullptr, *beta = nullptr;      // this layer's own factors (device; cin / cout entries, zero-padded)
     const float* gout = nullptr;                  // gauge of the output tensor = alpha of its 3x3x3 consumer (+ channel offset)
     const float* a_in = nullptr;                  // general kernels: gauge of the input tensor, folded into dw
@@ -107,7 +107,7 @@ struct nbe_ctx {
     nbe_progress_cb prog_cb = nullptr; void* prog_user = nullptr; int prog_k = 0, prog_n = 1;
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
-    bool gauge = false;                           // the loaded network is wired for gauged tangents (style, vel, f16x3)
+    bool gauge = false;                           // the loaded network is wired for gauged tangents (style weights, velocity, f32 / f16x3)
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
     int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
     // device-resident boxes of process_box

@@ -681,6 +681,13 @@ constexpr int HQ_XB = 2 * HQ_XT;                          // one patch buffer: X
 constexpr int HQ_XBASE = HQ_OFF_B + 2 * HQ_WB;
 constexpr int HQ_LDS_UNITS = HQ_XBASE + 2 * HQ_XB;        // 10048 units = 160,768 B
 
+// read one accumulator element where it is used (operand constraint "a": it stays in its AGPR until then)
+__device__ __forceinline__ float acc_read(const float& acc) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc));
+    return v;
+}
+
 // global -> LDS DMA with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit per-lane pointers
 __device__ __forceinline__ void dma16s(const char* ubase, unsigned voff, f32x4* dst_wave_base) {
     // pin the whole uniform address in SGPRs: otherwise its loop-invariant part is folded into a per-lane pointer
@@ -1205,19 +1212,19 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
             be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
             if (gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
         }
-        long o[4];
+        int o[4];                                                // voxel index in the output planes (< 2^31: tiles are <= 608^3)
         bool ook[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int yy = y0 + 2 * jq + (nt >> 1), xx = x0 + 16 * (nt & 1) + c;
             ook[nt] = yy < a.Hv && xx < a.Wv;
-            o[nt] = ook[nt] ? ((long)z * a.Ho + yy) * a.Wo + xx : (long)z * a.Ho * a.Wo;
+            o[nt] = ook[nt] ? (z * a.Ho + yy) * a.Wo + xx : z * a.Ho * a.Wo;
         }
         half4 rh[8], rl[8], dh[8], dl[8];
         if (res) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const long rb = ((long)(2 * unit[t >> 2]) * a.res_pstride + o[t & 3]) * 16 + 8 * kh;
+                const long rb = ((long)(2 * unit[t >> 2]) * a.res_pstride + (long)o[t & 3]) * 16 + 8 * kh;
                 const long rl_ = rb + a.res_pstride * 16;
                 rh[t] = *(const half4*)((const char*)a.r + rb);
                 rl[t] = *(const half4*)((const char*)a.r + rl_);
@@ -1229,11 +1236,15 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         for (int t = 0; t < 8; ++t) {
             const int mt = t >> 2, nt = t & 3;
             f32x4 v, dv;
+            // the accumulators leave their AGPRs tile by tile, here: copied out wholesale at the top of the epilogue (what
+            // the compiler does by itself) they do not fit beside the residuals and spill, and a scratch reload among
+            // the stores waits for every store before it
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float yp = ym[t][e] + yc[t][e] * H3_INV;
+                const float yp = acc_read(ym[t][e]) + acc_read(yc[t][e]) * H3_INV;
                 v[e] = yp + bv[mt][e];
-                dv[e] = dm[t][e] + dc[t][e] * H3_INV + be[mt][e] * yp;
+                dv[e] = acc_read(dm[t][e]) + acc_read(dc[t][e]) * H3_INV + be[mt][e] * yp;
             }
             if (res) { v += join4(rh[t], rl[t]); dv += join4(dh[t], dl[t]); }
             if (act) {
@@ -1248,7 +1259,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
                 for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
             }
             if (uok[mt] && ook[nt]) {
-                const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + o[nt]) * 16 + 8 * kh;
+                const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
                 const long ol = ob + a.out_pstride * 16;
                 half4 hi, lo;
                 split4(v, hi, lo);
