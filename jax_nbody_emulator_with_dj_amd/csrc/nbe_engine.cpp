@@ -107,7 +107,7 @@ struct nbe_ctx {
     nbe_progress_cb prog_cb = nullptr; void* prog_user = nullptr; int prog_k = 0, prog_n = 1;
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
-    bool gauge = false;                           // the loaded network is wired for gauged tangents (style weights, velocity, f32 / f16x3)
+    bool gauge = false;                           // the loaded network is wired for gauged tangents (style weights, velocity)
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
     int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
     // device-resident boxes of process_box
@@ -244,7 +244,7 @@ static void prof_collect(nbe_ctx* c) {
 static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false) {
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
     char b[96];
-    if (g6 && prec_is_half(pw.prec)) snprintf(b, sizeof b, "conv_h3g<%s,vel,dx>", m);
+    if (g6 && prec_is_half(pw.prec)) snprintf(b, sizeof b, "%s<%s,vel,dx>", pw.prec == PREC_F16 ? "conv_h1g" : "conv_h3g", m);
     else if (g6) snprintf(b, sizeof b, "conv_mfma_g<%s,vel,dx,ni%d>", m, pw.ni);
     else if (prec_is_half(pw.prec))
         snprintf(b, sizeof b, "%s<%s,%s,%s>", pw.prec == PREC_F16 ? "conv_h1" : "conv_h3", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx");
@@ -851,7 +851,7 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
     c->have_weights = true; c->style = style; c->modulated = !style;
     c->mod_Om = NAN; c->mod_Dz = NAN;
     const char* ge = getenv("NBE_GAUGE");
-    if (style && c->vel && c->prec != PREC_F16 && !(ge && atoi(ge) == 0)) return wire_gauge(c);
+    if (style && c->vel && !(ge && atoi(ge) == 0)) return wire_gauge(c);
     return 0;
 }
 

@@ -1325,8 +1325,11 @@ constexpr int H2_XBASE = H2_WA + H2_WB;
 constexpr int H2_LDS_UNITS = H2_XBASE + 2 * H2_XB;        // 7200 units = 115,200 B
 constexpr int H2_NPI = (H2_PL + 63) / 64;                 // DMA instructions per patch plane: 10 (the last one 36 lanes)
 
-template <bool SPLIT>
+// G6 (!SPLIT only): the input tangent arrives in this layer's gauge (see conv_h3g_kernel): dm += a0.b1 only, no dw operand,
+// dy = dm + beta * ym in the epilogue -- two products per tap instead of three.
+template <bool SPLIT, bool G6 = false>
 __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
+    static_assert(!(SPLIT && G6), "the gauged form belongs to the velocity variant");
     f32x4* lds = lds_h3;
     const half8* L8 = (const half8*)lds_h3;
     const int tid = threadIdx.x;
@@ -1348,6 +1351,7 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
         const int n = wave + 8 * t;
         if (n >= (second ? 16 : 20)) return;
         const int tap = (second ? 5 : 0) + (n >> 2), r = n & 3;
+        if (G6 && (r >> 1)) return;                              // no dw rows
         const char* src;
         if (SPLIT) {
             src = (const char*)a.w + (((long)ct * ngroups + g) * 9 * 4 + tap * 4 + r) * 64 * 16;
@@ -1432,17 +1436,17 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
     // flight; pre5 / pre6 request those of whatever follows (a0 and b1 in pre5, b0a in pre6).
     auto pair = [&](half8 (&A0)[2], int kind, int g, int gn, long xo, int nb, bool px, int wa, int xp,
                     auto&& pre5, auto&& pre6) {
-        LA(a1, wa + A1OFF + aP);
+        if (!G6) LA(a1, wa + A1OFF + aP);
         NBE_SB; MM8(acc1, A0, b1, 0, kind, 0, g, gn, xo, nb, px); NBE_SB;      // a0.b1, first half
         LB(b1, xp + B1OFF, 1);
         NBE_SB; MM8(acc0, A0, b0a, 0, kind, 2, g, gn, xo, nb, px); NBE_SB;     // a0.b0
         LB(b0b, xp, 1);
-        NBE_SB; MM8(acc1, a1, b0a, 0, kind, 4, g, gn, xo, nb, px); NBE_SB;     // a1.b0
-        MM8(acc1, A0, b1, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;                 // second half
+        if (!G6) { NBE_SB; MM8(acc1, a1, b0a, 0, kind, 4, g, gn, xo, nb, px); NBE_SB; }    // a1.b0
+        MM8(acc1, A0, b1, 1, G6 ? kind : 0, 4, g, gn, xo, nb, px); NBE_SB;     // second half (G6: the last DMA slots)
         pre5();
         NBE_SB; MM8(acc0, A0, b0b, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
         pre6();
-        NBE_SB; MM8(acc1, a1, b0b, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
+        if (!G6) { NBE_SB; MM8(acc1, a1, b0b, 1, 0, 0, g, gn, xo, nb, px); NBE_SB; }
     };
 
     // ---- prologue: the patch of group 0 and the weights of its first stage
@@ -1476,6 +1480,11 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
              [&] { LA(as, aS); LB(bsa, bS, 0); },
              [&] { LB(bsb, bS, 1); });
         LA(am, aM);
+        if (G6) {
+            const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            as[0] = ks ? zero : as[0];                                       // [a0 | 0]: a0.b1 only
+            as[1] = ks ? zero : as[1];
+        }
         NBE_SB; MM8(acc1, as, bsa, 0, 0, 0, g, gn, xo, nb, px); NBE_SB;        // a0.b1 + a1.b0
         MM8(acc1, as, bsb, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
         {
@@ -1504,13 +1513,16 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
         const bool act = a.flags & F_ACT, res = a.flags & F_RES;
         int unit[2];
         bool uok[2];
-        f32x4 bv[2];
+        f32x4 bv[2], be[2], gv[2];
+        const bool gauge = !SPLIT && a.gout != nullptr;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             unit[mt] = ct * 8 + 4 * it + 2 * mt + ks;
             uok[mt] = unit[mt] < a.cout_groups;
             if (!uok[mt]) unit[mt] = a.cout_groups - 1;
             bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
+            if (G6) be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
+            if (gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
         }
         long o[8];
         bool ook[8];
@@ -1539,6 +1551,7 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
             for (int e = 0; e < 4; ++e) {
                 v[e] = acc0[t][e] + (SPLIT ? acc1[t][e] * H3_INV : 0.f) + bv[mt][e];
                 dv[e] = SPLIT ? 0.f : acc1[t][e];
+                if (G6) dv[e] += be[mt][e] * acc0[t][e];
             }
             if (res) {
                 if (SPLIT) v += join4(r0[t], r1[t]);
@@ -1553,6 +1566,10 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
                     if (!SPLIT) dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
                     v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
                 }
+            }
+            if (gauge) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
             }
             if (uok[mt] && ook[nt]) {
                 const long ob = ((long)(a.out_g0 + PARTS * unit[mt]) * a.out_pstride + o[nt]) * 16 + 8 * kh;
@@ -1569,11 +1586,11 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
     }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool G6 = false>
 static void launch_h2q(ConvKArgs ka, int ctiles, hipStream_t s) {
     constexpr size_t smem = (size_t)H2_LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
-    auto kern = conv_h2q_kernel<SPLIT>;
+    auto kern = conv_h2q_kernel<SPLIT, G6>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1637,11 +1654,11 @@ void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_d
     else F<__VA_ARGS__, false, false>(ka, ct, s);
     static const bool shape32 = getenv("NBE_H3_SHAPE") && atoi(getenv("NBE_H3_SHAPE")) == 32;   // A/B: 32x32x16 MFMAs
     if (ka.beta) {                                               // gauged input tangent: only conv_h3g_kernel reads it
-        if (!(pw.mode == MODE_FLAT3 && split && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) {
+        if (!(pw.mode == MODE_FLAT3 && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) {
             fprintf(stderr, "nbe: internal error: gauged tangent passed to a layer without a gauged kernel\n");
             abort();
         }
-        launch_h3g(ka, ct, s);
+        if (split) launch_h3g(ka, ct, s); else launch_h2q<false, true>(ka, ct, s);
         return;
     }
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {

@@ -107,7 +107,7 @@ def test_gauged_tangent_paths(engine_factory, small, monkeypatch, prec):
     _check(dz, vz, dz_o[0], vz_o[0], "zero style factor")
 
 
-def test_float16_mode(engine_factory, small):
+def test_float16_mode(engine_factory, small, monkeypatch):
     """The float16 engine ("f16": float16 operands and stored activations, float32 accumulation -- the
     arithmetic of the reference's dtype=float16 configuration) against the float64 oracle.  Every one of the
     ~21 sequential layers rounds its operands to 11 significant bits, and the velocity is a tangent through
@@ -129,6 +129,14 @@ def test_float16_mode(engine_factory, small):
     e0.load_params(p, premodulated=False)
     e0.set_cosmology(OM, DZ)
     assert np.array_equal(e0.forward(x, DZ), d)                 # the primal does not depend on the tangent path
+    monkeypatch.setenv("NBE_GAUGE", "0")                        # three-product tangent (default: gauged, two products)
+    eg = engine_factory(mid_chan=8, compute_vel=True, precision="f16")
+    eg.load_params(p, premodulated=False)
+    eg.set_cosmology(OM, DZ)
+    dg, vg = eg.forward(x, DZ, VF)
+    monkeypatch.delenv("NBE_GAUGE")
+    print("f16 mid8, general tangent: vel rel_l2 %.3e; gauged vs general %.3e" % (rel_l2(vg, v_o), rel_l2(v, vg)))
+    assert np.array_equal(dg, d) and rel_l2(vg, v_o) <= 4e-2
 
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
     seed_p, seed_x, mid, d0, d1, d2_ = (int(t) for t in gold["net64_meta"])
