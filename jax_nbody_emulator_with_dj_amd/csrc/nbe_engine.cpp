@@ -790,6 +790,98 @@ static int wire_gauge(nbe_ctx* c) {
     return 0;
 }
 
+// Premodulated (W, dW) pairs: modulate_emulator_parameters_vel (nbody_emulator.py:221-266) produces dW = W (.) (alpha[ci] +
+// beta[co]) -- recognise that from the numbers (weighted alternating least squares for the additive model, then an
+// element-wise check) and run the gauged kernels; any 3x3x3 layer whose pair does not factorise to float32 rounding
+// (hand-made or perturbed dweight) leaves the whole network on the general three-product kernels.
+static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
+    std::map<std::string, std::vector<double>> al, be;
+    std::map<std::string, const nbe_layer_desc*> by_name;
+    for (int i = 0; i < n; ++i) by_name[std::string(descs[i].block) + "/" + descs[i].layer] = &descs[i];
+    for (const char* b : kBlocks) {
+        if (!strncmp(b, "down_", 5) || !strncmp(b, "up_", 3)) continue;
+        for (const char* l : {"conv_0", "conv_1"}) {
+            if (!strcmp(b, "conv_l00") && !strcmp(l, "conv_0")) continue;    // reads the input field: never gauged
+            const std::string key = std::string(b) + "/" + l;
+            const nbe_layer_desc& d = *by_name[key];
+            const int co = d.cout, ci = d.cin, k3 = d.k * d.k * d.k;
+            std::vector<double> a(ci, 0.0), bt(co, 0.0);
+            double dmax = 0.0;
+            for (size_t e = 0; e < (size_t)co * ci * k3; ++e) dmax = std::max(dmax, (double)std::fabs(d.dweight[e]));
+            for (int iter = 0; iter < 200; ++iter) {
+                double change = 0.0;
+                for (int i = 0; i < ci; ++i) {                           // alpha[i] = sum w (dW - W beta) / sum w^2 over (o, k)
+                    double num = 0.0, den = 0.0;
+                    for (int o = 0; o < co; ++o)
+                        for (int k = 0; k < k3; ++k) {
+                            const double w = d.weight[((size_t)o * ci + i) * k3 + k], dw = d.dweight[((size_t)o * ci + i) * k3 + k];
+                            num += w * (dw - w * bt[o]); den += w * w;
+                        }
+                    const double v = den > 0 ? num / den : 0.0;
+                    change = std::max(change, std::fabs(v - a[i])); a[i] = v;
+                }
+                for (int o = 0; o < co; ++o) {
+                    double num = 0.0, den = 0.0;
+                    for (int i = 0; i < ci; ++i)
+                        for (int k = 0; k < k3; ++k) {
+                            const double w = d.weight[((size_t)o * ci + i) * k3 + k], dw = d.dweight[((size_t)o * ci + i) * k3 + k];
+                            num += w * (dw - w * a[i]); den += w * w;
+                        }
+                    const double v = den > 0 ? num / den : 0.0;
+                    change = std::max(change, std::fabs(v - bt[o])); bt[o] = v;
+                }
+                if (change < 1e-13) break;
+            }
+            double res = 0.0;
+            for (int o = 0; o < co; ++o)
+                for (int i = 0; i < ci; ++i)
+                    for (int k = 0; k < k3; ++k) {
+                        const size_t e = ((size_t)o * ci + i) * k3 + k;
+                        res = std::max(res, std::fabs((double)d.dweight[e] - (double)d.weight[e] * (a[i] + bt[o])));
+                    }
+            if (!(res <= 2e-6 * dmax + 1e-30)) return 0;                 // does not factorise: keep the general kernels
+            al[key] = a; be[key] = bt;
+        }
+    }
+    if (wire_gauge(c)) return 1;
+    for (auto& kv : c->layers) {
+        Layer& L = kv.second;
+        auto ia = al.find(kv.first);
+        if (ia != al.end()) {
+            std::vector<float> fa(ia->second.begin(), ia->second.end()), fb(be[kv.first].begin(), be[kv.first].end());
+            HIPCHK(hipMemcpy(L.alpha, fa.data(), fa.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(L.beta, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    // general layers that read a gauged tensor: dW - W (.) a_in, a_in = alpha of the tensor's 3x3x3 reader (wire_gauge)
+    auto fold = [&](const char* b, const char* l, const char* reader, int off) -> int {
+        const std::string key = std::string(b) + "/" + l;
+        const nbe_layer_desc& d = *by_name[key];
+        Layer& L = c->layers[key];
+        const std::vector<double>& a = al[std::string(reader) + "/conv_0"];
+        const int k3 = d.k * d.k * d.k;
+        std::vector<float> eff((size_t)d.cout * d.cin * k3);
+        for (int o = 0; o < d.cout; ++o)
+            for (int i = 0; i < d.cin; ++i)
+                for (int k = 0; k < k3; ++k) {
+                    const size_t e = ((size_t)o * d.cin + i) * k3 + k;
+                    eff[e] = (float)((double)d.dweight[e] - (double)d.weight[e] * a[off + i]);
+                }
+        HIPCHK(hipMemcpy(L.dwn, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
+        launch_pack(L.dwn, d.cout, d.cin, L.kind, L.pw, L.pw.dw, c->stream);
+        return 0;
+    };
+    for (const char* b : kBlocks) {
+        if (!strncmp(b, "down_", 5) || !strncmp(b, "up_", 3) || !strcmp(b, "conv_l00")) continue;
+        if (fold(b, "skip", b, 0)) return 1;
+    }
+    if (fold("down_l0", "conv_0", "conv_r00", 0) || fold("down_l1", "conv_0", "conv_r1", 0) ||
+        fold("down_l2", "conv_0", "conv_r2", 0)) return 1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->gauge_active = true;
+    return 0;
+}
+
 static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool style) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -851,7 +943,7 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
     c->have_weights = true; c->style = style; c->modulated = !style;
     c->mod_Om = NAN; c->mod_Dz = NAN;
     const char* ge = getenv("NBE_GAUGE");
-    if (style && c->vel && !(ge && atoi(ge) == 0)) return wire_gauge(c);
+    if (c->vel && !(ge && atoi(ge) == 0)) return style ? wire_gauge(c) : wire_gauge_premod(c, descs, n);
     return 0;
 }
 

@@ -107,6 +107,37 @@ def test_gauged_tangent_paths(engine_factory, small, monkeypatch, prec):
     _check(dz, vz, dz_o[0], vz_o[0], "zero style factor")
 
 
+@pytest.mark.parametrize("prec", PRECS)
+def test_premodulated_pairs_are_recognised(engine_factory, small, prec):
+    """Premodulated (W, dW) pairs made by modulate_emulator_parameters_vel factorise as dW = W (alpha[ci] + beta[co]); the
+    engine recognises that from the numbers and runs the two-product kernels.  A pair that does not factorise (one
+    perturbed dweight element) must leave the network on the general kernels."""
+    import copy
+    from oracle import params as P
+    p, x, d_o, v_o = small
+    pp = P.premodulate_vel(p, 0.5, OM)
+
+    def run(params):
+        e = engine_factory(mid_chan=8, compute_vel=True, precision=prec)
+        e.load_params(params, premodulated=True)
+        e.profile_enable(True)
+        d, v = e.forward(x, DZ, VF)
+        e.profile_enable(False)
+        return d, v, any(k["kernel"].startswith(("conv_h3g", "conv_mfma_g")) for k in e.profile_read())
+
+    d, v, g = run(pp)
+    assert g, "factorising premodulated weights should run the gauged kernels"
+    _check(d, v, d_o, v_o, "premod gauged")
+    pq = copy.deepcopy(pp)
+    dw = pq["params"]["conv_l1"]["conv_0"]["dweight"]
+    dw = np.array(dw, copy=True)
+    dw[1, 2, 0, 1, 2] += 1e-3 * np.abs(dw).max()
+    pq["params"]["conv_l1"]["conv_0"]["dweight"] = dw
+    d2, v2, g2 = run(pq)
+    assert not g2, "a dweight that does not factorise must keep the general kernels"
+    assert rel_l2(d2, d) <= 2e-6 and rel_l2(v2, v_o) <= 1e-3
+
+
 def test_float16_mode(engine_factory, small, monkeypatch):
     """The float16 engine ("f16": float16 operands and stored activations, float32 accumulation -- the
     arithmetic of the reference's dtype=float16 configuration) against the float64 oracle.  Every one of the
