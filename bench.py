@@ -188,7 +188,7 @@ def main():
         gauged = dom["kernel"].startswith("conv_h3g<FLAT3,vel,dx")   # two-product tangent (default on the style path)
         if (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and gauged:
             if plan.startswith("(1, 1, 1)") and os.environ.get("NBE_PERIODIC", "1") != "0":
-                traffic = 58.3e9            # profiles/r01_pmc_fetch_write_default_gauged.txt
+                traffic = 52.9e9            # profiles/r01_pmc_fetch_write_default_gauged.txt
         elif (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
             if plan.startswith("(1, 1, 1)") and os.environ.get("NBE_PERIODIC", "1") != "0":
                 traffic = 59.6e9            # profiles/r01_pmc_fetch_write_default_periodic.txt

@@ -736,8 +736,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     // patch column and share two of their three input planes through that XCD's L2.  (Persistent workgroups were
     // measured on one device: a run of planes per workgroup loses that sharing, -12 %; a run of patches along x keeps
     // it but gains < 1 % over the same code with runs of one, and carrying the epilogue inside a loop costs 6 %.)
-    const int tile = xcd_tile(blockIdx.x, a.ntiles);
-    const int ct = blockIdx.y;
+    const int nct = (a.cout_groups + 7) / 8;                     // cout tiles of one patch side by side (see conv_h3g_kernel)
+    const int vt = xcd_tile(blockIdx.x, a.ntiles * nct);
+    const int tile = vt / nct, ct = vt - tile * nct;
     const int z = tile % a.Dv, tyx = tile / a.Dv;
     const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
     const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS;
@@ -1010,7 +1011,8 @@ static void launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
-    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    if (ctiles != (ka.cout_groups + 7) / 8) { fprintf(stderr, "nbe: internal error: cout tiling of conv_h3q_kernel\n"); abort(); }
+    dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(conv_h3q_kernel, grid, block, smem, s, ka);
 }
 
@@ -1048,8 +1050,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
     const int it = wave & 1, jq = wave >> 1;
 
-    const int tile = xcd_tile(blockIdx.x, a.ntiles);             // z fastest, as in conv_h3q_kernel
-    const int ct = blockIdx.y;
+    // cout tile fastest, then z (as in conv_h3q_kernel): the workgroups of one patch that differ only in their 64 couts
+    // run side by side on one XCD and share the patch through its L2 instead of fetching it from HBM once per cout tile
+    const int nct = (a.cout_groups + 7) / 8;
+    const int vt = xcd_tile(blockIdx.x, a.ntiles * nct);
+    const int tile = vt / nct, ct = vt - tile * nct;
     const int z = tile % a.Dv, tyx = tile / a.Dv;
     const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
     const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS;
@@ -1293,7 +1298,11 @@ static void launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
-    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    if (ctiles != (ka.cout_groups + 7) / 8) {
+        fprintf(stderr, "nbe: internal error: cout tiling of conv_h3g_kernel\n");
+        abort();
+    }
+    dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(conv_h3g_kernel, grid, block, smem, s, ka);
 }
 
@@ -1338,8 +1347,9 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
     const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
     const int it = wave & 1, jq = wave >> 1;
 
-    const int tile = xcd_tile(blockIdx.x, a.ntiles);             // (ty, tx, z), z fastest
-    const int ct = blockIdx.y;
+    const int nct = (a.cout_groups + 7) / 8;                     // cout tile fastest, then z (see conv_h3g_kernel)
+    const int vt = xcd_tile(blockIdx.x, a.ntiles * nct);
+    const int tile = vt / nct, ct = vt - tile * nct;
     const int z = tile % a.Dv, tyx = tile / a.Dv;
     const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
     const int y0 = ty * H2_ROWS, x0 = tx * HP_COLS;
@@ -1599,7 +1609,8 @@ static void launch_h2q(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tny = (ka.Hv + H2_ROWS - 1) / H2_ROWS;
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
-    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    if (ctiles != (ka.cout_groups + 7) / 8) { fprintf(stderr, "nbe: internal error: cout tiling of conv_h2q_kernel\n"); abort(); }
+    dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
 }
 
