@@ -840,6 +840,12 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
                         res = std::max(res, std::fabs((double)d.dweight[e] - (double)d.weight[e] * (a[i] + bt[o])));
                     }
             if (!(res <= 2e-6 * dmax + 1e-30)) return 0;                 // does not factorise: keep the general kernels
+            // alpha + c, beta - c is the same pair: centre alpha, and keep it small (the f16 formats store dx + alpha * x)
+            const double amin = *std::min_element(a.begin(), a.end()), amax = *std::max_element(a.begin(), a.end());
+            const double mid = 0.5 * (amin + amax);
+            for (double& v : a) v -= mid;
+            for (double& v : bt) v += mid;
+            if (amax - mid > 64.0) return 0;
             al[key] = a; be[key] = bt;
         }
     }

@@ -80,7 +80,7 @@ void launch_modulate(const float* weight, const float* style_weight, const float
                      int cout, int cin, int k3, float s0, float s1, float eps, int first_layer,
                      float* w_n, float* dw_tot /*nullable*/, hipStream_t s,
                      const float* a_in = nullptr, float* beta_out = nullptr);
-// alpha[ci] = (ds/dDz) / s of the style modulation of a layer; *flag |= 1 where s is (numerically) zero
+// alpha[ci] = (ds/dDz) / s of the style modulation of a layer; *flag |= 1 where s is (numerically) zero or |alpha| > 64
 void launch_style_alpha(const float* style_weight, const float* style_bias, int cin, float s0, float s1,
                         float* alpha, int* flag, hipStream_t s);
 // OIDHW -> packed layout; `kind`: 0 conv3, 1 skip(1x1x1), 2 down(k2 s2), 3 up(k2, 8 parity sets)

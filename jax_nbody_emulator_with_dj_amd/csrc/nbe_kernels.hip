@@ -353,7 +353,8 @@ __global__ void style_alpha_kernel(const float* __restrict__ sw, const float* __
     if (ci >= cin) return;
     const float smod = sw[2 * ci] * s0 + sw[2 * ci + 1] * s1 + sb[ci];
     const float al = sw[2 * ci + 1] / smod;
-    const bool ok = fabsf(smod) > 1e-20f && isfinite(al);
+    // |alpha| is capped as well: the f16-based formats store dx + alpha * x, which must stay far inside the f16 range
+    const bool ok = fabsf(smod) > 1e-20f && isfinite(al) && fabsf(al) <= 64.f;
     alpha[ci] = ok ? al : 0.f;
     if (!ok) atomicOr(flag, 1);
 }

@@ -106,6 +106,15 @@ def test_gauged_tangent_paths(engine_factory, small, monkeypatch, prec):
     assert not gz, "a zero style factor must switch the gauged kernels off"
     _check(dz, vz, dz_o[0], vz_o[0], "zero style factor")
 
+    # a style factor that is merely tiny: alpha = s'/s = 1000 would push dx + alpha x towards the float16 range
+    pt = copy.deepcopy(p)
+    pt["params"]["conv_r1"]["conv_0"]["style_weight"][5] = (0.0, 1.0)
+    pt["params"]["conv_r1"]["conv_0"]["style_bias"][5] = -(DZ - 1.0) + 1e-3
+    dt_o, vt_o = M.forward(pt, x[None], OM, DZ, VF)
+    dt, vt, gt = run(pt)
+    assert not gt, "|alpha| > 64 must switch the gauged kernels off"
+    _check(dt, vt, dt_o[0], vt_o[0], "tiny style factor")
+
 
 @pytest.mark.parametrize("prec", PRECS)
 def test_premodulated_pairs_are_recognised(engine_factory, small, prec):
