@@ -212,3 +212,32 @@ def test_process_box_golden_and_ndiv_independence():
     dis1, vel1 = S.process_box(p, box, Z, OM, (s0, s1, s2), (1, 1, 1))
     np.testing.assert_allclose(dis1, dis, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(vel1, vel, rtol=1e-9, atol=1e-9)
+
+
+def test_style_tangent_weight_factorises():
+    """The identity behind the engine's two-product ("gauged") tangent, checked on the oracle in float64:
+    dw[o,i,k] = w_n[o,i,k] * (alpha[i] + beta[o]) with alpha = s'/s, beta = -sum (w s)(w s') / norm^2
+    (style_layers_vel.py:62-101), hence W.dx + dW.x = W.(dx + alpha*x) + beta*(W.x) for any x, dx."""
+    from oracle import layers as L
+    rng = np.random.default_rng(21)
+    co, ci, k = 6, 5, 3
+    w0 = rng.standard_normal((co, ci, k, k, k))
+    sw = rng.standard_normal((ci, 2)) / np.sqrt(ci)
+    sb = 1.0 + 0.1 * rng.standard_normal(ci)
+    s = L.style_vector(0.31, 0.77)
+    for first in (False, True):
+        w_n, dw = L.modulate_weights_vel(sw, sb, w0, s, first)
+        smod = sw @ s + sb
+        alpha = sw[:, 1] / smod
+        wmod = w0 * smod[None, :, None, None, None]
+        norm2 = np.sum(wmod * wmod, axis=(1, 2, 3, 4)) + 1e-8
+        beta = -np.sum(wmod * (w0 * sw[:, 1][None, :, None, None, None]), axis=(1, 2, 3, 4)) / norm2
+        if first:
+            beta = beta + 1.0 / (s[1] + 1.0)                 # the first layer's input scale is one more [o]-independent term
+        fact = w_n * (alpha[None, :, None, None, None] + beta[:, None, None, None, None])
+        assert np.max(np.abs(fact - dw)) <= 1e-12 * np.max(np.abs(dw))
+        x, dx = rng.standard_normal((2, ci, k, k, k))
+        lhs = np.einsum("oizyx,izyx->o", w_n, dx) + np.einsum("oizyx,izyx->o", dw, x)
+        xg = dx + alpha[:, None, None, None] * x
+        rhs = np.einsum("oizyx,izyx->o", w_n, xg) + beta * np.einsum("oizyx,izyx->o", w_n, x)
+        assert np.max(np.abs(lhs - rhs)) <= 1e-12 * np.max(np.abs(lhs))
