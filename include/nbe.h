@@ -5,8 +5,8 @@
  * to the reference repository root); the Python shim in jax_nbody_emulator_with_dj_amd/ binds them with
  * ctypes.
  *
- * Conventions: every function returns 0 on success and a non-zero code on failure; the message is
- * available from nbe_last_error() (thread local).  Tensors are float32, C-contiguous, channel-first
+ * Conventions: every function returns 0 on success and a non-zero code on failure (1 = error, 2 = NBE_ERANGE, see
+ * "Range" below); the message is available from nbe_last_error() (thread local).  No entry point aborts the process.  Tensors are float32, C-contiguous, channel-first
  * ((C, D, H, W)) exactly as the reference passes them.  Data pointers may be host OR device pointers
  * (detected with hipPointerGetAttributes); the caller owns them.  The library owns all device memory it
  * allocates.  One in-flight call per context; several contexts may coexist (one per GPU / stream).
@@ -70,6 +70,36 @@ int nbe_set_arch(nbe_ctx* ctx, int in_chan, int out_chan, int mid_chan, float ep
  *                   the reference's SubboxConfig.dtype = float16 configuration (its fastest rows, README.md:245-250) */
 enum { NBE_PREC_F32 = 0, NBE_PREC_F16X3 = 1, NBE_PREC_F16 = 2 };
 int nbe_set_precision(nbe_ctx* ctx, int precision);
+
+/* Range of the f16-based modes (NBE_PREC_F16X3, NBE_PREC_F16).  Their operands are f16 numbers (|v| < 65504, full
+ * precision above 6.1e-5), while the reference's float32 arithmetic (style_layers_vel.py:103-105) has float32's range.
+ * The engine therefore shifts every call into f16's comfortable range: LeakyReLU is positively homogeneous and the
+ * convolutions are linear, so f(s x; s b) = s f(x; b) for the network f with input x and biases b, exactly in floating
+ * point for s = 2^k.  Per call k is chosen such that max(max|x| * Dz / 6, max|b|) * 2^k lies in [0.5, 1): a reduction
+ * over the input, the input scaled in the gather, the biases scaled on the device, 2^-k applied in the head.  Valid
+ * inputs: any finite float32 box -- parity with the float64 oracle is tested over 24 decades of input scale
+ * (tests/test_gpu_range.py).  What remains out of range is a network whose activations grow beyond 65504 times its
+ * largest input / bias (weights far from the unit-norm filters the modulation produces); then an infinity or a NaN
+ * reaches the head, which flags it:
+ *   - host arrays in/out: the call returns NBE_ERANGE (2) instead of the fields;
+ *   - device pointers (asynchronous calls): nbe_check_finite() synchronises and returns NBE_ERANGE if any call since
+ *     the last check produced a non-finite value from a finite input.  The Python shim calls it after every call and
+ *     recomputes that call on a strict-float32 context (never a silent inf / NaN).
+ * Non-finite INPUT values propagate to the outputs as in the reference and are not an error.
+ * nbe_set_input_range(ctx, m): use m as max|x| instead of reducing over the input (ranks of a sharded box agree on one
+ * value with an all-reduce so that every brick is computed with the same shift); m < 0 returns to the reduction. */
+enum { NBE_ERANGE = 2 };
+int nbe_check_finite(nbe_ctx* ctx);
+int nbe_set_input_range(nbe_ctx* ctx, float absmax);
+
+/* state of the context after the last call / plan: see the enum */
+enum { NBE_Q_GAUGE_ACTIVE = 0,     /* 1: the loaded weights run the two-product (gauged) tangent kernels             */
+       NBE_Q_SLAB = 1,             /* planes per z-slab of the last plan (0 = whole tensors)                          */
+       NBE_Q_PERIODIC_YX = 2,      /* 1: the last plan runs periodic in y and x                                       */
+       NBE_Q_PERIODIC_Z = 3,       /* 1: ... and in z                                                                 */
+       NBE_Q_RANGE_SHIFT = 4,      /* k of the last call's range shift 2^k                                            */
+       NBE_Q_WORKSPACE_BYTES = 5 };
+int nbe_query(nbe_ctx* ctx, int what, double* out);
 
 /* replaces model.apply's `params` argument for the Style* cores (README.md:155; subbox.py:224-233) */
 int nbe_load_style_weights(nbe_ctx* ctx, const nbe_layer_desc* layers, int nlayers);

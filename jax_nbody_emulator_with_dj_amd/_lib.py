@@ -19,6 +19,10 @@ class NBEError(RuntimeError):
     pass
 
 
+class NBERangeError(NBEError):
+    """A call on an f16-based context produced non-finite values from a finite input (include/nbe.h, "Range")."""
+
+
 class LayerDesc(C.Structure):
     _fields_ = [
         ("block", C.c_char_p), ("layer", C.c_char_p),
@@ -59,6 +63,9 @@ SIGNATURES = {
     "nbe_set_slab": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_set_periodic": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "nbe_check_finite": (C.c_int, [C.c_void_p]),
+    "nbe_set_input_range": (C.c_int, [C.c_void_p, C.c_float]),
+    "nbe_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "nbe_growth_factor": (C.c_double, [C.c_double, C.c_double]),
     "nbe_vel_norm": (C.c_double, [C.c_double, C.c_double]),
     "nbe_test_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -114,4 +121,5 @@ def lib():
 
 def check(rc):
     if rc != 0:
-        raise NBEError(lib().nbe_last_error().decode("utf-8", "replace"))
+        msg = lib().nbe_last_error().decode("utf-8", "replace")
+        raise (NBERangeError if rc == 2 else NBEError)(msg)

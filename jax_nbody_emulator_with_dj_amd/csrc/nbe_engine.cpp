@@ -76,6 +76,7 @@ struct Layer {
     float *wn = nullptr, *dwn = nullptr;          // modulated OIDHW (device)
     PackedW pw;
     // tangent gauge (style path, see conv_h3g_kernel): dw = w_n (.) (alpha[ci] + beta[co])
+    float* bias0 = nullptr;                       // the bias as loaded (device, padded like pw.bias, which holds bias0 * act_scale)
     float *alpha = nullptr, *beta = nullptr;      // this layer's own factors (device; cin / cout entries, zero-padded)
     const float* gout = nullptr;                  // gauge of the output tensor = alpha of its 3x3x3 consumer (+ channel offset)
     const float* a_in = nullptr;                  // general kernels: gauge of the input tensor, folded into dw
@@ -110,6 +111,16 @@ struct nbe_ctx {
     bool gauge = false;                           // the loaded network is wired for gauged tangents (style weights, velocity)
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
     int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
+    // Range shift of the f16-based arithmetic (include/nbe.h, "Range"): activations and biases of a call are multiplied
+    // by act_scale = 2^k (exact), the head divides it out.  flags[0]: bit pattern of max |input| (launch_absmax),
+    // flags[1]: a non-finite value was written by the head.
+    float act_scale = 1.f;                        // 2^k of the current call
+    float bias_scale = 1.f;                       // 2^k the device biases currently carry
+    float bias_max = 0.f;                         // max |bias| over all layers (host, at load time)
+    float preset_absmax = -1.f;                   // >= 0: max |input| supplied by the caller (nbe_set_input_range)
+    bool input_finite = true;                     // the input of the current call had no NaN / infinity
+    bool range_pending = false;                   // a call has run since the last nbe_check_finite
+    unsigned* flags = nullptr;                    // device: [0] absmax bits, [1] non-finite output
     // device-resident boxes of process_box
     float* box_in = nullptr; int64_t box_in_bytes = 0;
     char* box_out = nullptr; int64_t box_out_bytes = 0;
@@ -254,8 +265,8 @@ static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 =
 }
 
 // launch one convolution layer (or record it in a dry run)
-static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool has_dx) {
-    if (c->dry) return;
+static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool has_dx) {
+    if (c->dry) return 0;
     ConvLaunch cl = cl_in;
     // timing experiments of NBE_DBG builds (bits >= 8); production kernels ignore them
     static const int dbgf = getenv("NBE_DEBUG_FLAGS") ? atoi(getenv("NBE_DEBUG_FLAGS")) & 0xF00 : 0;
@@ -268,7 +279,9 @@ static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool h
         ea = get_event(c); eb = get_event(c);
         (void)hipEventRecord(ea, c->stream);
     }
-    launch_conv(L.pw, cl, c->vel, has_dx, c->stream);
+    if (launch_conv(L.pw, cl, c->vel, has_dx, c->stream))
+        return fail("internal error: no kernel for layer %s/%s (mode %d, gauged %d, input tangent %d, crop offset %ld, output stride %d)",
+                    L.block.c_str(), L.layer.c_str(), L.pw.mode, (int)g6, (int)has_dx, (long)cl.in_off, cl.osz);
     if (c->prof) {
         (void)hipEventRecord(eb, c->stream);
         c->pending.push_back({pe, ea, eb});
@@ -281,6 +294,7 @@ static void run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool h
         c->prof_entries[pe].launches += 1;
         if (c->pending.size() > 4096) prof_collect(c);
     }
+    return 0;
 }
 
 static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer) {
@@ -313,17 +327,17 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     {
         ConvLaunch cl; cl.in = x.p; cl.in_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
         cl.Dv = D - 4; cl.Hv = Hi - 2 * sy; cl.Wv = Wi - 2 * sy; cl.out = inner(s); cl.flags = 0;
-        run_conv(c, *Ls, cl, has_dx);
+        if (run_conv(c, *Ls, cl, has_dx)) return 1;
     }
     {
         ConvLaunch cl; cl.in = x.p; cl.Dv = D - 2; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = inner(h); cl.flags = F_ACT;
-        run_conv(c, *L0, cl, has_dx);
+        if (run_conv(c, *L0, cl, has_dx)) return 1;
     }
     fill_halo(c, h);
     {
         ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = h.p.H - 2; cl.Wv = h.p.W - 2; cl.out = inner(s);
         cl.res = inner(s); cl.flags = F_RES | (final_act ? F_ACT : 0);
-        run_conv(c, *L1, cl, true);
+        if (run_conv(c, *L1, cl, true)) return 1;
     }
     fill_halo(c, s);
     tfree(c, h);
@@ -344,17 +358,17 @@ static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Te
     {
         ConvLaunch cl; cl.in = zview(x, js, ns + 4).p; cl.in_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
         cl.Dv = ns; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(sv); cl.flags = 0;
-        run_conv(c, *Ls, cl, has_dx);
+        if (run_conv(c, *Ls, cl, has_dx)) return 1;
     }
     {
         ConvLaunch cl; cl.in = zview(x, jh, nh + 2).p; cl.Dv = nh; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = inner(hv); cl.flags = F_ACT;
-        run_conv(c, *L0, cl, has_dx);
+        if (run_conv(c, *L0, cl, has_dx)) return 1;
     }
     fill_halo(c, hv);
     {
         ConvLaunch cl; cl.in = zview(h, js, ns + 2).p; cl.Dv = ns; cl.Hv = h.p.H - 2; cl.Wv = h.p.W - 2; cl.out = inner(sv);
         cl.res = inner(sv); cl.flags = F_RES | (final_act ? F_ACT : 0);
-        run_conv(c, *L1, cl, true);
+        if (run_conv(c, *L1, cl, true)) return 1;
     }
     fill_halo(c, sv);
     return 0;
@@ -372,7 +386,7 @@ static int downblock(nbe_ctx* c, const char* name, const Tensor& x, Tensor* out)
     Tensor o = talloc(c, c->mid, x.p.D / 2, x.p.H / 2, x.p.W / 2);
     if (o.off < 0) return fail("workspace exhausted in %s", name);
     ConvLaunch cl; cl.in = x.p; cl.Dv = o.p.D; cl.Hv = o.p.H; cl.Wv = o.p.W; cl.out = o.p; cl.flags = F_ACT;
-    run_conv(c, *L, cl, true);
+    if (run_conv(c, *L, cl, true)) return 1;
     *out = o;
     return 0;
 }
@@ -391,7 +405,7 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
         cl.Dv = x.p.D; cl.Hv = Hx; cl.Wv = Wx; cl.out = inner(cat);
         cl.out_g0 = c->mid / (c->prec == PREC_F16 ? 8 : 4); cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
         cl.flags = F_ACT; cl.set = p;
-        run_conv(c, *L, cl, true);
+        if (run_conv(c, *L, cl, true)) return 1;
     }
     return 0;
 }
@@ -468,8 +482,74 @@ struct HeadOut { void* disp; void* velo; int out_dtype; int OD, OH, OW, a0, a1, 
 
 static void run_head(nbe_ctx* c, const Tensor& y, const Tensor& xin, const HeadOut& h, int zoff) {
     if (c->dry) return;
-    launch_head(y.p, xin.p, 48, c->out_chan, h.Dz, h.vel_fac, c->vel, h.disp, h.velo, h.out_dtype, h.OD, h.OH, h.OW,
+    // core :187-193 with the call's range shift s = 2^k divided out (exact): disp = (y + x0) * 6 / s,
+    // vel = dy * (vf * 6 / s) + x0 * (vf * 6 / (Dz * s))
+    const float inv_s = 1.0f / c->act_scale;
+    HeadScale hs;
+    hs.k_disp = 6.0f * inv_s; hs.k_dy = h.vel_fac * 6.0f * inv_s; hs.k_x0 = h.vel_fac * 6.0f / h.Dz * inv_s;
+    hs.bad = c->flags ? (int*)(c->flags + 1) : nullptr;
+    launch_head(y.p, xin.p, 48, c->out_chan, hs, c->vel, h.disp, h.velo, h.out_dtype, h.OD, h.OH, h.OW,
                 h.a0 + zoff, h.a1, h.a2, c->prec, c->stream, y.pad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Range shift (include/nbe.h, "Range").  LeakyReLU is positively homogeneous and the convolutions are linear, so the
+// network with input x and biases b satisfies f(s x; s b) = s f(x; b) for s > 0, exactly in floating point when s is a
+// power of two.  The f16-based modes use that to keep their operands where f16 has both range and precision: s = 2^k
+// brings max(|x| Dz / 6, max |b|) into [0.5, 1) whatever the caller's units are.
+// ------------------------------------------------------------------------------------------------
+static int prepare_range(nbe_ctx* c, const float* dev_src, int64_t n, float Dz) {
+    c->input_finite = true;
+    float s = 1.f;
+    if (prec_is_half(c->prec)) {
+        if (!c->flags) { HIPCHK(hipMalloc((void**)&c->flags, 8)); HIPCHK(hipMemsetAsync(c->flags, 0, 8, c->stream)); }
+        float amax = c->preset_absmax;
+        if (amax < 0.f) {
+            HIPCHK(hipMemsetAsync(c->flags, 0, 4, c->stream));
+            launch_absmax(dev_src, n, c->flags, c->stream);
+            unsigned bits = 0;
+            HIPCHK(hipMemcpyAsync(&bits, c->flags, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            memcpy(&amax, &bits, 4);
+        }
+        if (!std::isfinite(amax)) c->input_finite = false;     // NaN / infinity in: NaN / infinity out, as in the reference
+        else {
+            const float m = std::max(amax * std::fabs(Dz) / 6.0f, c->bias_max);
+            if (m > 0.f && std::isfinite(m)) {
+                int e = 0;
+                (void)std::frexp(m, &e);                        // m = f * 2^e, f in [0.5, 1)
+                e = std::max(-100, std::min(100, e));
+                s = std::ldexp(1.0f, -e);
+            }
+        }
+    }
+    c->act_scale = s;
+    if (s != c->bias_scale) {
+        for (auto& kv : c->layers) {
+            Layer& L = kv.second;
+            launch_scale(L.bias0, L.pw.bias, L.pw.ctiles * 32 * L.pw.ni, s, c->stream);
+        }
+        c->bias_scale = s;
+    }
+    c->range_pending = true;
+    return 0;
+}
+
+// after a call: did the head write a non-finite value although the input was finite?  (synchronises the stream)
+static int check_range(nbe_ctx* c) {
+    if (!c->range_pending || !c->flags) { c->range_pending = false; return 0; }
+    c->range_pending = false;
+    unsigned bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, c->flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemsetAsync(c->flags + 1, 0, 4, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad && c->input_finite) {
+        fail("non-finite values in the output of a finite input: an activation left the range of the %s arithmetic "
+             "(|value| >= 65504 * 2^%d after the range shift); rerun this call with NBE_PREC_F32",
+             c->prec == PREC_F16 ? "float16" : "f16x3", -(int)std::lround(std::log2(c->act_scale)));
+        return 2;
+    }
+    return 0;
 }
 
 // The same network with the two full-resolution levels run in slabs of S output planes (S even): the encoder blocks
@@ -540,7 +620,7 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
                 const Tensor tv = zview(td, (d0 - (pz ? 44 : 0)) / 2, (d1 - d0) / 2);
                 Tensor yv = zview(y0, d0 - z, d1 - d0);
                 ConvLaunch cl; cl.in = inner(yv); cl.Dv = tv.p.D; cl.Hv = tv.p.H; cl.Wv = tv.p.W; cl.out = tv.p; cl.flags = F_ACT;
-                run_conv(c, *Ld, cl, true);
+                if (run_conv(c, *Ld, cl, true)) return 1;
             }
         }
     }
@@ -571,7 +651,7 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
         const Layer* Ld1 = find_layer(c, "down_l1", "conv_0");
         if (t2.off < 0 || !Ld1) return fail("workspace exhausted or missing layer (down_l1)");
         ConvLaunch cl; cl.in = inner(y1); cl.Dv = t2.p.D; cl.Hv = t2.p.H; cl.Wv = t2.p.W; cl.out = t2.p; cl.flags = F_ACT;
-        run_conv(c, *Ld1, cl, true);
+        if (run_conv(c, *Ld1, cl, true)) return 1;
         t = talloc(c, m, t2.p.D, t2.p.H + 20, t2.p.W + 20);
         if (t.off < 0) return fail("workspace exhausted (level 2 input)");
         if (!c->dry) launch_wrap_pad(t2.p, t.p, 10, c->vel, c->stream, 0);
@@ -696,7 +776,7 @@ static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int 
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
     tin.pad = c->pyx ? 1 : 0;                                   // periodic-yx: (H, W) = box extent + 2, gathered from origin - 1
     // core :132-134: x = x * (Dz / 6)
-    launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f, c->prec, c->stream);
+    launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
     const HeadOut ho{disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, Dz, vel_fac};
     if (c->slab > 0) return network_stream(c, tin, ho, c->slab);
     if (network(c, tin, &y)) return 1;
@@ -711,10 +791,11 @@ static void free_layers(nbe_ctx* c) {
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
-        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias);
+        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0);
         (void)hipFree(L.alpha); (void)hipFree(L.beta);
     }
     c->layers.clear();
+    c->bias_scale = 1.f; c->bias_max = 0.f;
     c->have_weights = false; c->modulated = false; c->gauge = false; c->gauge_active = false;
 }
 
@@ -919,6 +1000,10 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
         HIPCHK(hipMalloc((void**)&pw.bias, nb * 4));
         HIPCHK(hipMemset(pw.bias, 0, nb * 4));
         HIPCHK(hipMemcpy(pw.bias, d.bias, d.cout * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&L.bias0, nb * 4));
+        HIPCHK(hipMemcpy(L.bias0, pw.bias, nb * 4, hipMemcpyDeviceToDevice));
+        for (int i = 0; i < d.cout; ++i)
+            if (std::isfinite(d.bias[i])) c->bias_max = std::max(c->bias_max, std::fabs(d.bias[i]));
         HIPCHK(hipMalloc((void**)&L.wn, nw * 4));
         if (c->vel) HIPCHK(hipMalloc((void**)&L.dwn, nw * 4));
         if (style) {
@@ -989,7 +1074,7 @@ int nbe_destroy(nbe_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     free_layers(c);
-    (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag);
+    (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag); (void)hipFree(c->flags);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1095,13 +1180,17 @@ int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float 
         if (need > c->box_out_bytes) { (void)hipFree(c->box_out); HIPCHK(hipMalloc((void**)&c->box_out, need)); c->box_out_bytes = need; }
         dd = c->box_out; vd = c->box_out + out_bytes;
     }
+    if (prepare_range(c, xd, (int64_t)c->in_chan * D * H * W, Dz)) return 1;
     if (run_subbox(c, xd, D, H, W, 0, 0, 0, D, H, W, Dz, vel_fac, dd, vd, NBE_F32, OD, OH, OW, 0, 0, 0)) return 1;
     HIPCHK(hipGetLastError());
     if (!out_dev) {
         HIPCHK(hipMemcpyAsync(disp, dd, out_bytes, hipMemcpyDeviceToHost, c->stream));
         if (c->vel) HIPCHK(hipMemcpyAsync(vel, vd, out_bytes, hipMemcpyDeviceToHost, c->stream));
     }
-    if (!out_dev || !xin_dev) HIPCHK(hipStreamSynchronize(c->stream));
+    if (!out_dev || !xin_dev) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return check_range(c);                                  // host arrays: the call is synchronous anyway
+    }
     return 0;
 }
 
@@ -1356,6 +1445,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         HIPCHK(hipMemsetAsync(dd, 0, out_bytes, c->stream));
         if (c->vel) HIPCHK(hipMemsetAsync(vd, 0, out_bytes, c->stream));
     }
+    if (prepare_range(c, bd, (int64_t)c->in_chan * S0 * S1 * S2, Dz)) return 1;
     const int total = ndiv[0] * ndiv[1] * ndiv[2];
     const int n = order ? norder : total;
     for (int k = 0; k < n; ++k) {
@@ -1375,7 +1465,10 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         HIPCHK(hipMemcpyAsync(disp, dd, out_bytes, hipMemcpyDeviceToHost, c->stream));
         if (c->vel) HIPCHK(hipMemcpyAsync(vel, vd, out_bytes, hipMemcpyDeviceToHost, c->stream));
     }
-    if (!out_dev || !in_dev) HIPCHK(hipStreamSynchronize(c->stream));
+    if (!out_dev || !in_dev) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return check_range(c);                                  // host arrays: the call is synchronous anyway
+    }
     return 0;
 }
 
@@ -1396,6 +1489,32 @@ int nbe_process_region(nbe_ctx* c, const void* box, const int64_t box_size[3], c
     if (!c || !box || !disp || !box_size || !origin || !region || !ndiv || !out_size || !out_origin) return fail("null argument");
     return process_region(c, box, box_size, origin, region, ndiv, order, norder, Dz, vel_fac, disp, vel, out_dtype,
                           out_size, out_origin, false, nullptr, nullptr);
+}
+
+int nbe_check_finite(nbe_ctx* c) {
+    if (!c) return fail("null context");
+    HIPCHK(hipSetDevice(c->device));
+    return check_range(c);
+}
+
+int nbe_set_input_range(nbe_ctx* c, float absmax) {
+    if (!c) return fail("null context");
+    c->preset_absmax = (absmax >= 0.f || std::isnan(absmax)) ? absmax : -1.f;
+    return 0;
+}
+
+int nbe_query(nbe_ctx* c, int what, double* out) {
+    if (!c || !out) return fail("null argument");
+    switch (what) {
+    case NBE_Q_GAUGE_ACTIVE: *out = c->gauge_active ? 1 : 0; break;
+    case NBE_Q_SLAB: *out = c->slab; break;
+    case NBE_Q_PERIODIC_YX: *out = c->pyx ? 1 : 0; break;
+    case NBE_Q_PERIODIC_Z: *out = c->pz ? 1 : 0; break;
+    case NBE_Q_RANGE_SHIFT: *out = std::log2((double)c->act_scale); break;
+    case NBE_Q_WORKSPACE_BYTES: *out = (double)c->ws_bytes; break;
+    default: return fail("nbe_query: unknown item %d", what);
+    }
+    return 0;
 }
 
 // ---- test hooks -----------------------------------------------------------------------------------
@@ -1484,15 +1603,16 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
             TCHK(hipStreamSynchronize(c->stream));
         }
         ConvLaunch cl; cl.in = pin; cl.out = pout; cl.res = pres; cl.flags = flags;
-        if (kind == 0) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; run_conv(c, L, cl, has_dx); }
-        else if (kind == 1) { cl.in_off = ((int64_t)crop * H + crop) * W + crop; cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; run_conv(c, L, cl, has_dx); }
-        else if (kind == 2) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; run_conv(c, L, cl, has_dx); }
+        if (kind == 0) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; rc = run_conv(c, L, cl, has_dx); }
+        else if (kind == 1) { cl.in_off = ((int64_t)crop * H + crop) * W + crop; cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; rc = run_conv(c, L, cl, has_dx); }
+        else if (kind == 2) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; rc = run_conv(c, L, cl, has_dx); }
         else {
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < 8 && !rc; ++p) {
                 ConvLaunch u = cl; u.Dv = D; u.Hv = H; u.Wv = W; u.osz = 2; u.oz = (p >> 2) & 1; u.oy = (p >> 1) & 1; u.ox = p & 1; u.set = p;
-                run_conv(c, L, u, has_dx);
+                rc = run_conv(c, L, u, has_dx);
             }
         }
+        if (rc) break;
         launch_from_planes(pout, false, cout, dout, c->prec, c->stream);
         TCHK(hipStreamSynchronize(c->stream));
         TCHK(hipMemcpy(y, dout, nout * 4, hipMemcpyDeviceToHost));

@@ -72,7 +72,8 @@ struct ConvLaunch {
     const float* beta = nullptr;   // gauged input: two-product tangent with this per-cout factor (3x3x3 f16x3 only)
 };
 
-void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, hipStream_t s);
+// 0 on success; 1 = the layer / flag combination has no kernel (an engine bug, reported through nbe_last_error)
+int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, hipStream_t s);
 
 // weight preparation -------------------------------------------------------
 // (w_n, dw_tot) in OIDHW from raw style parameters (style_layers_vel.py:62-105)
@@ -97,10 +98,18 @@ void launch_from_planes(const Planes& src, bool tangent, int C, float* dst, int 
 // (cz >= 0: crop along z by cz instead of c -- the z-slab schedule copies plane ranges)
 void launch_crop(const Planes& src, int c, const Planes& dst, int g0, bool vel, hipStream_t s, int cz = -1);
 // head: disp = (y + x0)*6 ; vel = dy*(vf*6) + x0*(vf*6/Dz); x0 = input planes cropped by `c0`;
-// written to a (C, Db, Hb, Wb) box at origin (a0,a1,a2); out_dtype 0 = f32, 1 = f16
-void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+// written to a (C, Db, Hb, Wb) box at origin (a0,a1,a2); out_dtype 0 = f32, 1 = f16.
+// The three factors arrive ready-made (k_disp = 6/s, k_dy = vf*6/s, k_x0 = vf*6/(Dz*s), s = the power-of-two range
+// shift of the call); *bad |= 1 when a non-finite value is written (nullable).
+struct HeadScale { float k_disp = 6.f, k_dy = 0.f, k_x0 = 0.f; int* bad = nullptr; };
+void launch_head(const Planes& y, const Planes& xin, int c0, int C, const HeadScale& hs, bool vel,
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
                  int prec, hipStream_t s, int pad = 0);
+// *out_bits = max(*out_bits, bit pattern of |src[i]|) over n floats (non-negative floats order like their bit
+// patterns; a NaN or an infinity gives >= 0x7f800000)
+void launch_absmax(const float* src, int64_t n, unsigned* out_bits, hipStream_t s);
+// dst[i] = src[i] * f
+void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s);
 
 // periodic y/x halo of width `pad` of a tensor whose interior has been written; dst = src extended periodically in y/x
 void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s);

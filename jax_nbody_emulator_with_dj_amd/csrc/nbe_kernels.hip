@@ -20,6 +20,8 @@
 // The tangent (velocity) path shares every staged operand: y += W.X, dy += dW.X + W.dX.
 
 #include "nbe_kernels_internal.h"
+#include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -235,7 +237,7 @@ static void launch_conv_t(const ConvKArgs& ka, int ctiles, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
 }
 
-void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, hipStream_t s) {
+int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, hipStream_t s) {
     ConvKArgs ka;
     ka.x = L.in.x; ka.dx = L.in.dx; ka.in_pstride = L.in.pstride;
     ka.D = L.in.D; ka.H = L.in.H; ka.W = L.in.W; ka.P = L.in.vox(); ka.in_off = L.in_off;
@@ -253,16 +255,13 @@ void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, 
     ka.flags = L.flags;
     ka.gout = L.gout; ka.beta = L.beta;
     ka.ntiles = (int)((ka.Q + TILE_VOX - 1) / TILE_VOX);
-    if (prec_is_half(pw.prec)) { launch_conv_h3(pw, ka, vel, has_dx, s); return; }
+    if (prec_is_half(pw.prec)) return launch_conv_h3(pw, ka, vel, has_dx, s);
     const int ct = pw.ctiles;
     if (ka.beta) {                                               // gauged input tangent: 3x3x3 layers only
-        if (!(pw.mode == MODE_FLAT3 && vel && has_dx)) {
-            fprintf(stderr, "nbe: internal error: gauged tangent passed to a layer without a gauged kernel\n");
-            abort();
-        }
+        if (!(pw.mode == MODE_FLAT3 && vel && has_dx)) return 1;   // no gauged kernel for this layer: the caller reports it
         if (pw.ni == 2) launch_conv_t<MODE_FLAT3, true, true, 2, true>(ka, ct, s);
         else launch_conv_t<MODE_FLAT3, true, true, 1, true>(ka, ct, s);
-        return;
+        return 0;
     }
 #define NBE_DISPATCH(MODE)                                                                   \
     if (vel) {                                                                               \
@@ -278,6 +277,7 @@ void launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, 
     else if (pw.mode == MODE_FLAT1) { NBE_DISPATCH(MODE_FLAT1) }
     else { NBE_DISPATCH(MODE_DOWN) }
 #undef NBE_DISPATCH
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,9 +545,9 @@ template <typename OT>
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                    long ypstride, int D, int H, int W,
                                                    const float* __restrict__ xin, long xpstride, int XH, int XW,
-                                                   int c0, int C, float k_dy, float k_x0, OT* __restrict__ disp,
-                                                   OT* __restrict__ velo, int Db, int Hb, int Wb, int a0, int a1,
-                                                   int a2, int pad) {
+                                                   int c0, int C, float k_disp, float k_dy, float k_x0,
+                                                   OT* __restrict__ disp, OT* __restrict__ velo, int Db, int Hb, int Wb,
+                                                   int a0, int a1, int a2, int pad, int* __restrict__ bad) {
     // pad > 0: y and xin carry a periodic y/x halo of `pad` voxels; the loop runs over the interior
     const int Hi = H - 2 * pad, Wi = W - 2 * pad, c1 = pad > 0 ? pad : c0;
     const long vi = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, 
     const long xv = ((long)(z + c0) * XH + (yy + c1)) * XW + (x + c1);
     const long bo = ((long)(a0 + z) * Hb + (a1 + yy)) * Wb + (a2 + x);
     const long bstride = (long)Db * Hb * Wb;
+    bool nf = false;
     for (int g = 0; 4 * g < C; ++g) {
         const f32x4 yv = *(const f32x4*)(y + ((long)g * ypstride + v) * 4);
         const f32x4 x0 = *(const f32x4*)(xin + ((long)g * xpstride + xv) * 4);
@@ -567,28 +568,71 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ y, 
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * g + e;
             if (c < C) {
-                disp[c * bstride + bo] = (OT)((yv[e] + x0[e]) * 6.0f);
-                if (dy) velo[c * bstride + bo] = (OT)(dv[e] * k_dy + x0[e] * k_x0);
+                const float dsp = (yv[e] + x0[e]) * k_disp;
+                disp[c * bstride + bo] = (OT)dsp;
+                nf = nf || !isfinite(dsp);
+                if (dy) {
+                    const float vv = dv[e] * k_dy + x0[e] * k_x0;
+                    velo[c * bstride + bo] = (OT)vv;
+                    nf = nf || !isfinite(vv);
+                }
             }
         }
     }
+    if (nf && bad) atomicOr(bad, 1);
 }
 
-void launch_head(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+void launch_head(const Planes& y, const Planes& xin, int c0, int C, const HeadScale& hs, bool vel,
                  void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
                  int prec, hipStream_t s, int pad) {
-    if (prec_is_half(prec)) { launch_head_h8(y, xin, c0, C, Dz, vel_fac, vel, disp, velo, out_dtype, Db, Hb, Wb, a0, a1, a2, prec_parts(prec), s, pad); return; }
+    if (prec_is_half(prec)) { launch_head_h8(y, xin, c0, C, hs, vel, disp, velo, out_dtype, Db, Hb, Wb, a0, a1, a2, prec_parts(prec), s, pad); return; }
     const long V = (long)y.D * (y.H - 2 * pad) * (y.W - 2 * pad);
-    const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
     dim3 grid((unsigned)((V + 255) / 256)), block(256);
     if (out_dtype == 0)
         hipLaunchKernelGGL(head_kernel<float>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D, y.H,
-                           y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (float*)disp, (float*)velo,
-                           Db, Hb, Wb, a0, a1, a2, pad);
+                           y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, hs.k_disp, hs.k_dy, hs.k_x0, (float*)disp,
+                           (float*)velo, Db, Hb, Wb, a0, a1, a2, pad, hs.bad);
     else
         hipLaunchKernelGGL(head_kernel<_Float16>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D,
-                           y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (_Float16*)disp,
-                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, pad);
+                           y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, hs.k_disp, hs.k_dy, hs.k_x0,
+                           (_Float16*)disp, (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, pad, hs.bad);
+}
+
+// max |x| of a float array as a bit pattern (grid-stride, 16 B per lane, wave shuffle reduction, one atomic per wave)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, long n, unsigned* __restrict__ out) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    unsigned m = 0;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const uint4 v = *(const uint4*)(src + 4 * i);
+        m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(src[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_down((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+void launch_absmax(const float* src, int64_t n, unsigned* out_bits, hipStream_t s) {
+    if (n <= 0) return;
+    // 16-byte loads need a 16-byte aligned base: hipMalloc / torch allocations are; anything else goes scalar
+    if (((uintptr_t)src & 15) != 0) {
+        const long head = std::min<long>(n, (16 - ((uintptr_t)src & 15)) / 4);
+        hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, s, src, head, out_bits);   // 1..3 elements: the tail path
+        if (head >= n) return;
+        src += head; n -= head;
+    }
+    const unsigned blocks = (unsigned)std::min<long>(2048, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, (long)n, out_bits);
+}
+
+__global__ void scale_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] * f;
+}
+
+void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, f);
 }
 
 }  // namespace nbe

@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
 #undef NBE_STAGE_END
 }
 
-static void launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
+static int launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
     constexpr size_t smem = (size_t)HQ_LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static bool attr_done = false;
@@ -1011,9 +1011,10 @@ static void launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
-    if (ctiles != (ka.cout_groups + 7) / 8) { fprintf(stderr, "nbe: internal error: cout tiling of conv_h3q_kernel\n"); abort(); }
+    if (ctiles != (ka.cout_groups + 7) / 8) return 1;            // cout tiling mismatch: reported by the caller
     dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(conv_h3q_kernel, grid, block, smem, s, ka);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1288,7 +1289,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 #undef NBE_STAMP
 }
 
-static void launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
+static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
     constexpr size_t smem = (size_t)HQ_LDS_UNITS * 16;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1298,12 +1299,10 @@ static void launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
-    if (ctiles != (ka.cout_groups + 7) / 8) {
-        fprintf(stderr, "nbe: internal error: cout tiling of conv_h3g_kernel\n");
-        abort();
-    }
+    if (ctiles != (ka.cout_groups + 7) / 8) return 1;
     dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(conv_h3g_kernel, grid, block, smem, s, ka);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1597,7 +1596,7 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
 }
 
 template <bool SPLIT, bool G6 = false>
-static void launch_h2q(ConvKArgs ka, int ctiles, hipStream_t s) {
+static int launch_h2q(ConvKArgs ka, int ctiles, hipStream_t s) {
     constexpr size_t smem = (size_t)H2_LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     auto kern = conv_h2q_kernel<SPLIT, G6>;
@@ -1609,9 +1608,10 @@ static void launch_h2q(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tny = (ka.Hv + H2_ROWS - 1) / H2_ROWS;
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
-    if (ctiles != (ka.cout_groups + 7) / 8) { fprintf(stderr, "nbe: internal error: cout tiling of conv_h2q_kernel\n"); abort(); }
+    if (ctiles != (ka.cout_groups + 7) / 8) return 1;
     dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(kern, grid, block, smem, s, ka);
+    return 0;
 }
 
 template <int MODE, bool VEL, bool HAS_DX, int XDEPTH, bool SPLIT>
@@ -1654,7 +1654,7 @@ static void launch_h3p_v(const ConvKArgs& ka, int ct, hipStream_t s) { launch_h3
 template <int MODE, int XDEPTH, bool SPLIT, bool VEL, bool HAS_DX>
 static void launch_h3_v(const ConvKArgs& ka, int ct, hipStream_t s) { launch_h3_t<MODE, VEL, HAS_DX, XDEPTH, SPLIT>(ka, ct, s); }
 
-void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
+int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
     const int ct = pw.ctiles;
     static const int depth = (getenv("NBE_H3_DEPTH") && atoi(getenv("NBE_H3_DEPTH")) == 3) ? 3 : 2;
     static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
@@ -1665,21 +1665,17 @@ void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_d
     else F<__VA_ARGS__, false, false>(ka, ct, s);
     static const bool shape32 = getenv("NBE_H3_SHAPE") && atoi(getenv("NBE_H3_SHAPE")) == 32;   // A/B: 32x32x16 MFMAs
     if (ka.beta) {                                               // gauged input tangent: only conv_h3g_kernel reads it
-        if (!(pw.mode == MODE_FLAT3 && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) {
-            fprintf(stderr, "nbe: internal error: gauged tangent passed to a layer without a gauged kernel\n");
-            abort();
-        }
-        if (split) launch_h3g(ka, ct, s); else launch_h2q<false, true>(ka, ct, s);
-        return;
+        if (!(pw.mode == MODE_FLAT3 && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) return 1;   // no gauged kernel
+        return split ? launch_h3g(ka, ct, s) : launch_h2q<false, true>(ka, ct, s);
     }
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
-        if (split && vel && has_dx && !shape32 && sched == 0) { launch_h3q(ka, ct, s); return; }
-        if (split && !vel && !shape32) { launch_h2q<true>(ka, ct, s); return; }
-        if (!split && vel && has_dx && !shape32) { launch_h2q<false>(ka, ct, s); return; }
+        if (split && vel && has_dx && !shape32 && sched == 0) return launch_h3q(ka, ct, s);
+        if (split && !vel && !shape32) return launch_h2q<true>(ka, ct, s);
+        if (!split && vel && has_dx && !shape32) return launch_h2q<false>(ka, ct, s);
         if (!split) { NBE_VD(launch_h3p_v, 0, false) }
         else if (sched == 1) { NBE_VD(launch_h3p_v, 1, true) }
         else { NBE_VD(launch_h3p_v, 0, true) }
-        return;
+        return 0;
     }
     if (pw.mode == MODE_FLAT3) {
         if (!split) { NBE_VD(launch_h3_v, MODE_FLAT3, 2, false) }
@@ -1691,6 +1687,7 @@ void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_d
         if (!split) { NBE_VD(launch_h3_v, MODE_DOWN, 2, false) } else { NBE_VD(launch_h3_v, MODE_DOWN, 2, true) }
     }
 #undef NBE_VD
+    return 0;
 }
 
 // packed layout: [set][ct][stage = chunk*nseg + seg][tap][u = 2*h + part][co 64][j 8];
@@ -1799,9 +1796,10 @@ template <typename OT>
 __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                       long ypstride, int D, int H, int W,
                                                       const float* __restrict__ xin, long xpstride, int XH, int XW,
-                                                      int c0, int C, float k_dy, float k_x0, OT* __restrict__ disp,
-                                                      OT* __restrict__ velo, int Db, int Hb, int Wb, int a0, int a1,
-                                                      int a2, int parts, int pad) {
+                                                      int c0, int C, float k_disp, float k_dy, float k_x0,
+                                                      OT* __restrict__ disp, OT* __restrict__ velo, int Db, int Hb,
+                                                      int Wb, int a0, int a1, int a2, int parts, int pad,
+                                                      int* __restrict__ bad) {
     // pad > 0: y and xin carry a periodic y/x halo of `pad` voxels; the loop runs over the interior
     const int Hi = H - 2 * pad, Wi = W - 2 * pad, c1 = pad > 0 ? pad : c0;
     const long vi = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1812,6 +1810,7 @@ __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ 
     const long xv = ((long)(z + c0) * XH + (yy + c1)) * XW + (x + c1);
     const long bo = ((long)(a0 + z) * Hb + (a1 + yy)) * Wb + (a2 + x);
     const long bstride = (long)Db * Hb * Wb;
+    bool nf = false;
     for (int g = 0; 8 * g < C; ++g) {
         const half8 yh = ld8(y, parts * g, ypstride, v), xh = ld8(xin, parts * g, xpstride, xv);
         const half8 yl = parts == 2 ? ld8(y, 2 * g + 1, ypstride, v) : yh;
@@ -1823,27 +1822,34 @@ __global__ __launch_bounds__(256) void head_h8_kernel(const float* __restrict__ 
             const int c = 8 * g + e;
             if (c < C) {
                 const float yv = join1(yh, yl, e, parts), x0 = join1(xh, xl, e, parts);
-                disp[c * bstride + bo] = (OT)((yv + x0) * 6.0f);
-                if (dy) velo[c * bstride + bo] = (OT)(join1(dh, dl, e, parts) * k_dy + x0 * k_x0);
+                const float dsp = (yv + x0) * k_disp;
+                disp[c * bstride + bo] = (OT)dsp;
+                nf = nf || !isfinite(dsp);
+                if (dy) {
+                    const float vv = join1(dh, dl, e, parts) * k_dy + x0 * k_x0;
+                    velo[c * bstride + bo] = (OT)vv;
+                    nf = nf || !isfinite(vv);
+                }
             }
         }
     }
+    // an operand beyond the f16 range became an infinity on its way through the network (see nbe.h, "Range")
+    if (nf && bad) atomicOr(bad, 1);
 }
 
-void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, const HeadScale& hs, bool vel,
                     void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
                     int parts, hipStream_t s, int pad) {
     const long V = (long)y.D * (y.H - 2 * pad) * (y.W - 2 * pad);
-    const float k_dy = vel_fac * 6.0f, k_x0 = vel_fac * 6.0f / Dz;
     dim3 grid((unsigned)((V + 255) / 256)), block(256);
     if (out_dtype == 0)
         hipLaunchKernelGGL(head_h8_kernel<float>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D, y.H,
-                           y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (float*)disp, (float*)velo,
-                           Db, Hb, Wb, a0, a1, a2, parts, pad);
+                           y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, hs.k_disp, hs.k_dy, hs.k_x0, (float*)disp,
+                           (float*)velo, Db, Hb, Wb, a0, a1, a2, parts, pad, hs.bad);
     else
         hipLaunchKernelGGL(head_h8_kernel<_Float16>, grid, block, 0, s, y.x, vel ? y.dx : nullptr, y.pstride, y.D,
-                           y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, k_dy, k_x0, (_Float16*)disp,
-                           (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, parts, pad);
+                           y.H, y.W, xin.x, xin.pstride, xin.H, xin.W, c0, C, hs.k_disp, hs.k_dy, hs.k_x0,
+                           (_Float16*)disp, (_Float16*)velo, Db, Hb, Wb, a0, a1, a2, parts, pad, hs.bad);
 }
 
 }  // namespace nbe

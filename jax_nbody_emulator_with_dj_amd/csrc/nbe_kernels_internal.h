@@ -41,12 +41,12 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {
 }
 
 // f16x3 path (nbe_kernels_h3.hip)
-void launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s);
+int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s);
 void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s);
 void launch_gather_h8(const float* box, int C, int Db, int Hb, int Wb, int a0, int a1, int a2,
                       float* dst, const Planes& geom, float scale, int parts, hipStream_t s);
 void launch_from_planes_h8(const float* src, const Planes& geom, int C, float* dst, int parts, hipStream_t s);
-void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, float Dz, float vel_fac, bool vel,
+void launch_head_h8(const Planes& y, const Planes& xin, int c0, int C, const HeadScale& hs, bool vel,
                     void* disp, void* velo, int out_dtype, int Db, int Hb, int Wb, int a0, int a1, int a2,
                     int parts, hipStream_t s, int pad = 0);
 

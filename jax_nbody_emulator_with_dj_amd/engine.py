@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import LayerDesc, NBEError, check
+from ._lib import LayerDesc, NBEError, NBERangeError, check   # noqa: F401  (re-exported)
 
 try:  # torch is optional plumbing: device buffers + streams for resident / multi-GPU runs
     import torch
@@ -32,17 +32,31 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+try:
+    from xxhash import xxh3_64_intdigest as _digest          # ~10 GB/s: 13 MB of weights in about a millisecond
+except Exception:  # pragma: no cover
+    from zlib import crc32 as _digest
+
+
+def _leaf_digest(a):
+    a = np.asarray(a)
+    if not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a)
+    return (a.shape, a.dtype.str, _digest(memoryview(a).cast('B')))
+
+
 def params_fingerprint(params):
-    """Cheap identity of a parameter tree: callers re-assign `.params` after construction
-    (reference tests/test_nbody_emulator.py:807,832), so weights are re-read lazily."""
+    """Content fingerprint of a parameter tree (shape, dtype and a 64-bit checksum of every leaf).  Callers re-assign
+    `.params` after construction (reference tests/test_nbody_emulator.py:807,832) and NumPy leaves are mutable, so the
+    weights on the GPU are checked against the tree on every call; identity (`id`) is not enough -- an array edited
+    in place keeps its id, and a freed tree's ids are recycled.  The reference re-reads `params` on every call."""
     tree = params['params'] if 'params' in params else params
     fp = []
     for b in sorted(tree):
         for l in sorted(tree[b]):
             for k in sorted(tree[b][l]):
-                a = tree[b][l][k]
-                fp.append((b, l, k, id(a)))
-    return (id(tree), tuple(fp))
+                fp.append((b, l, k) + _leaf_digest(tree[b][l][k]))
+    return tuple(fp)
 
 
 class Engine:
@@ -121,8 +135,13 @@ class Engine:
         arr = (LayerDesc * len(descs))(*descs)
         fn = self._l.nbe_load_premod_weights if premodulated else self._l.nbe_load_style_weights
         check(fn(self._h, arr, len(descs)))
+        self._keep = keep                # the library copies the weights; the float32 copies live as long as the load
         self.loaded = params_fingerprint(params)
         self.premodulated = bool(premodulated)
+
+    def invalidate(self):
+        """Forget what is loaded: the next call re-uploads the parameter tree."""
+        self.loaded = None
 
     def ensure_params(self, params, premodulated):
         if params is None:
@@ -167,10 +186,31 @@ class Engine:
     def synchronize(self):
         check(self._l.nbe_synchronize(self._h))
 
-    def _follow_torch_stream(self):
-        """CUDA tensors in/out: enqueue on torch's current stream so that torch ops before and after
-        this call are ordered with the kernels (device pointers make the C calls asynchronous)."""
-        sp = int(torch.cuda.current_stream().cuda_stream)      # 0 = torch's default = the null stream
+    QUERY = {"gauge_active": 0, "slab": 1, "periodic_yx": 2, "periodic_z": 3, "range_shift": 4, "workspace_bytes": 5}
+
+    def query(self, what):
+        """State of the context after the last call / plan (include/nbe.h, nbe_query)."""
+        out = C.c_double()
+        check(self._l.nbe_query(self._h, self.QUERY[what], C.byref(out)))
+        return out.value
+
+    def check_finite(self):
+        """Synchronise and raise NBERangeError if a call since the last check produced non-finite values from a finite
+        input (f16-based arithmetic, include/nbe.h "Range").  Host-array calls check themselves."""
+        check(self._l.nbe_check_finite(self._h))
+
+    def set_input_range(self, absmax):
+        """max |input| of the following calls (None: the engine reduces over the input itself).  Ranks of a sharded box
+        agree on one value so that every brick is computed with the same range shift."""
+        check(self._l.nbe_set_input_range(self._h, -1.0 if absmax is None else float(absmax)))
+
+    def _follow_torch_stream(self, t=None):
+        """CUDA tensors in/out: enqueue on torch's current stream OF THIS ENGINE'S DEVICE so that torch ops before and
+        after this call are ordered with the kernels (device pointers make the C calls asynchronous)."""
+        if t is not None and (t.device.index or 0) != self.device:
+            raise NBEError("tensor lives on cuda:%d but this engine was created for cuda:%d"
+                           % (t.device.index or 0, self.device))
+        sp = int(torch.cuda.current_stream(self.device).cuda_stream)      # 0 = torch's default = the null stream
         if getattr(self, '_stream_ptr', None) != sp:
             self.set_stream(sp)
 
@@ -184,7 +224,7 @@ class Engine:
         if min(oshape) <= 0:
             raise NBEError("input %s is smaller than the receptive field (needs > 96 per axis)" % (tuple(x.shape),))
         if _is_torch(x):
-            self._follow_torch_stream()
+            self._follow_torch_stream(x)
             x = x.contiguous().float()
             disp = torch.empty(oshape, dtype=torch.float32, device=x.device)
             vel = torch.empty(oshape, dtype=torch.float32, device=x.device) if self.compute_vel else None
@@ -193,10 +233,12 @@ class Engine:
             disp = np.empty(oshape, np.float32)
             vel = np.empty(oshape, np.float32) if self.compute_vel else None
         check(self._l.nbe_forward(self._h, _ptr(x), D, H, W, float(Dz), float(vel_fac), _ptr(disp), _ptr(vel)))
+        if _is_torch(x):
+            self.check_finite()
         return (disp, vel) if self.compute_vel else disp
 
     def process_box(self, box, size, ndiv, padding, Dz, vel_fac=0.0, out_dtype=np.float32, progress=None,
-                    out=None):
+                    out=None, check_finite=True):
         size = tuple(int(s) for s in size)
         if tuple(box.shape) != (self.in_chan,) + size:
             raise NBEError("input_box shape %s does not match (in_chan,)+size = %s" % (tuple(box.shape), (self.in_chan,) + size))
@@ -205,7 +247,7 @@ class Engine:
             raise NBEError("output dtype %s unsupported (float32 / float16)" % np.dtype(out_dtype))
         oshape = (self.out_chan,) + size
         if _is_torch(box):
-            self._follow_torch_stream()
+            self._follow_torch_stream(box)
             box = box.contiguous().float()
             tdt = torch.float16 if half else torch.float32
             if out is not None:
@@ -223,12 +265,15 @@ class Engine:
         cb = _lib.PROGRESS_CB(progress) if progress is not None else C.cast(None, _lib.PROGRESS_CB)
         check(self._l.nbe_process_box(self._h, _ptr(box), sz, nd, pd, float(Dz), float(vel_fac), _ptr(disp),
                                       _ptr(vel), 1 if half else 0, cb, None))
+        if _is_torch(box) and check_finite:     # device tensors: the call is asynchronous; check_finite=False defers it
+            self.check_finite()
         return (disp, vel) if self.compute_vel else disp
 
     def process_region(self, box, origin, region, ndiv, Dz, vel_fac, disp, vel, out_origin=(0, 0, 0), order=None):
         """Run (a subset of) the sub-boxes tiling `region` of the periodic array `box` (CUDA tensors);
-        results land in disp / vel (CUDA tensors) at out_origin + anchor.  Asynchronous on the engine's stream."""
-        self._follow_torch_stream()
+        results land in disp / vel (CUDA tensors) at out_origin + anchor.  Asynchronous on the engine's stream
+        (call check_finite() when the step is complete)."""
+        self._follow_torch_stream(box)
         i64 = lambda t: (C.c_int64 * 3)(*[int(v) for v in t])
         half = disp.element_size() == 2
         nd = (C.c_int * 3)(*[int(n) for n in ndiv])

@@ -135,7 +135,16 @@ class _Core:
             is_t = False
         if is_t and device is None:
             device = x.device.index or 0
-        eng = get_engine(self, device, precision_for(x.dtype))
+        prec = precision_for(x.dtype)
+        try:
+            return self._run_on(get_engine(self, device, prec), params, x, Om, Dz, vel_fac, is_t)
+        except _engine.NBERangeError as e:
+            # an activation left the f16 range (include/nbe.h, "Range"): the strict float32 engine has float32's range
+            import warnings
+            warnings.warn("%s -- recomputing this call with the strict float32 engine" % e, RuntimeWarning)
+            return self._run_on(get_engine(self, device, "f32"), params, x, Om, Dz, vel_fac, is_t)
+
+    def _run_on(self, eng, params, x, Om, Dz, vel_fac, is_t):
         eng.ensure_params(params, self._premodulate)
         B = x.shape[0]
         bc = lambda v: None if v is None else np.broadcast_to(np.atleast_1d(np.asarray(v, dtype=np.float32)).ravel(), (B,))

@@ -70,17 +70,21 @@ def load_default_parameters():
     Load default pretrained model parameters (reference nbody_emulator.py:115-129).
 
     The reference ships them as an .npz holding a pickled nested dict.  The blob is not part of
-    this repository (it is absent from the reference checkout too); place it at
-    `jax_nbody_emulator_with_dj_amd/model_parameters/nbody_emulator_params.npz`.
+    this repository (it is absent from the reference checkout too); place it -- as it is, or converted to the
+    pickle-free flat format with `python -m jax_nbody_emulator_with_dj_amd.params_io` -- at
+    `jax_nbody_emulator_with_dj_amd/model_parameters/nbody_emulator_params.npz`
+    (or point the environment variable NBE_PARAMS at it).  Either format is read without executing anything
+    from the file (params_io.py).
     """
-    params_path = Path(__file__).parent / "model_parameters" / "nbody_emulator_params.npz"
+    import os
+    params_path = Path(os.environ.get("NBE_PARAMS") or
+                       Path(__file__).parent / "model_parameters" / "nbody_emulator_params.npz")
     if not params_path.exists():
         raise FileNotFoundError(
             "pretrained parameters not found at %s (the blob is not distributed with this repository); "
             "use create_emulator(load_params=False) and assign emulator.params / processor.params" % params_path)
-    with np.load(params_path, allow_pickle=True) as f:     # our own file format, same as the reference's
-        params = f['params'].item()
-    return {'params': params}
+    from .params_io import load_parameters
+    return load_parameters(params_path)                    # flat .npz or the reference's pickled dict; no code is executed
 
 
 def _style_vector(z, Om):

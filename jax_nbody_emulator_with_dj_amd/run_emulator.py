@@ -140,7 +140,8 @@ def build_parser():
                     help='Output file precision: f16 (half) or f32 (full) (default: f16).')
     ap.add_argument('--quiet', '-q', action='store_true', help='Suppress progress bars (useful for batch jobs)')
     ap.add_argument('--params', type=Path, default=None,
-                    help="Parameter tree (.npz with a pickled {'params': ...} dict, the reference's format); "
+                    help="Parameter tree: flat .npz (block/layer/leaf arrays, see params_io.py) or the reference's "
+                         ".npz with a pickled {'params': ...} dict (read with a restricted unpickler); "
                          'default: the packaged pretrained blob')
     return ap
 
@@ -149,9 +150,8 @@ def load_params(path):
     from .nbody_emulator import load_default_parameters
     if path is None:
         return load_default_parameters()
-    with np.load(path, allow_pickle=True) as f:        # a file the user names explicitly, reference format
-        tree = f['params'].item()
-    return tree if 'params' in tree else {'params': tree}
+    from .params_io import load_parameters
+    return load_parameters(path)                       # flat .npz or the reference's format; nothing is executed
 
 
 def run(args):

@@ -88,7 +88,7 @@ def exchange_halo(brick, grid, coords, pad=PAD, group=None, pad_unsplit=True):
     b = (b0, b1, b2)
     pa = tuple(pad if (grid[a] > 1 or pad_unsplit) else 0 for a in range(3))
     for a in range(3):
-        if b[a] < pad:
+        if pa[a] > 0 and b[a] < pad:                # axes without a halo (unsplit, pad_unsplit=False) may be any size
             raise ValueError("brick extent %d along axis %d is smaller than the halo %d" % (b[a], a, pad))
     H = torch.empty((C, b0 + 2 * pa[0], b1 + 2 * pa[1], b2 + 2 * pa[2]), dtype=brick.dtype, device=brick.device)
     H[:, pa[0]:pa[0] + b0, pa[1]:pa[1] + b1, pa[2]:pa[2] + b2] = brick
@@ -165,10 +165,18 @@ class ShardedBox:
         self.group = group
         self.comm_stream = comm_stream
 
-    def process(self, brick, Dz, vel_fac, disp, vel):
+    def process(self, brick, Dz, vel_fac, disp, vel, check_finite=True):
         """brick, disp, vel: CUDA tensors (C, *bshape).  Interior sub-boxes run while the halo
         messages are in flight on the communication stream; boundary sub-boxes wait for them."""
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream(brick.device)
+        # one range shift for the whole box (include/nbe.h, "Range"): max |x| over all bricks, a 4-byte all-reduce --
+        # every rank then computes its brick with the arithmetic a single-GPU run of the box would use
+        amax = torch.linalg.vector_norm(brick.reshape(-1), ord=float('inf')).float().reshape(1)
+        if self.world > 1:
+            if dist.get_backend(self.group) == "gloo":
+                amax = amax.cpu()
+            dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)
+        self.eng.set_input_range(float(amax.item()))
         # the engine merges sub-boxes into larger tiles when that is exact (nbe_plan_tiles); split on that grid
         nd = self.eng.plan_tiles(self.bshape, self.nd_local, periodic_box=False)
         interior, boundary = split_interior(nd, self.bshape)
@@ -188,4 +196,6 @@ class ShardedBox:
         # haloed only along the split axes: along the others the region is the periodic box itself
         origin = tuple(PAD if g > 1 else 0 for g in self.grid)
         self.eng.process_region(H, origin, self.bshape, nd, Dz, vel_fac, disp, vel, order=sorted(boundary))
+        if check_finite:
+            self.eng.check_finite()              # synchronises; raises NBERangeError instead of returning inf / NaN
         return disp, vel

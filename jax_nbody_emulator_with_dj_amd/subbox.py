@@ -114,7 +114,18 @@ class SubboxProcessor:
         if is_t and not input_box.is_cuda:
             input_box, is_t = input_box.numpy(), False
         device = (input_box.device.index or 0) if is_t else None
-        eng = _models.get_engine(self.model, device, _models.precision_for(cfg.dtype))
+        try:
+            return self._process_on(_models.get_engine(self.model, device, _models.precision_for(cfg.dtype)),
+                                    input_box, is_t, z, Om, desc, show_progress)
+        except _engine.NBERangeError as e:
+            # an activation left the f16 range (include/nbe.h, "Range"): the strict float32 engine has float32's range
+            import warnings
+            warnings.warn("%s -- recomputing this box with the strict float32 engine" % e, RuntimeWarning)
+            return self._process_on(_models.get_engine(self.model, device, "f32"), input_box, is_t, z, Om, desc,
+                                    show_progress)
+
+    def _process_on(self, eng, input_box, is_t, z, Om, desc, show_progress):
+        cfg = self.config
         eng.ensure_params(self.params, self.premodulate)
 
         # cosmology once per box (subbox.py:173-178), float32 like the reference
