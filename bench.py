@@ -71,6 +71,7 @@ def main():
                          "whole-network error vs the float64 oracle equal to or below the strict path's; "
                          "f32: strict float32 MFMA")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 reference pass")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-array (NumPy in / NumPy out) pass")
     args = ap.parse_args()
 
     import torch
@@ -173,6 +174,11 @@ def main():
         eng.close()
         return dt, prof, ok, plan
 
+    def traffic_key(precision, plan):
+        """What a PMC traffic figure was measured on (besides the kernel sources): tools/pmc_traffic.py --bench-json"""
+        return "process_box %d^3 ndiv %d vel=%s precision=%s plan=%s periodic=%s" % (
+            N, args.ndiv, vel, precision, plan.split(" tiles")[0], os.environ.get("NBE_PERIODIC", "1"))
+
     def roofline(prof, precision, plan=""):
         # dominant kernel, from HIP events recorded on the engine's stream inside the timed region.
         # f16x3 issues three f16 MFMAs per float32 product: algorithmic FLOPs are priced against 1/3 of the
@@ -181,28 +187,59 @@ def main():
         tot_ms = sum(e["ms"] for e in prof)
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0, "f16": PEAK_F16_MFMA_TFLOPS}[precision]
-        # HBM-side bytes per launch of the dominant kernel cannot be read from inside the process; they come from
-        # the committed rocprofv3 --pmc passes of this exact workload (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # see the file named beside each value) and are reported only when the configuration matches.
+        # HBM-side bytes per launch of the dominant kernel cannot be read from inside the process: they come from the
+        # committed rocprofv3 --pmc passes of this exact workload (profiles/traffic.json, written by tools/pmc_traffic.py:
+        # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) and are reported only while that file was measured on the kernel
+        # sources this run uses (source hash) and on this workload; otherwise null.
         traffic = None
-        gauged = dom["kernel"].startswith("conv_h3g<FLAT3,vel,dx")   # two-product tangent (default on the style path)
-        if (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and gauged:
-            if plan.startswith("(1, 1, 1)") and os.environ.get("NBE_PERIODIC", "1") != "0":
-                traffic = 52.9e9            # profiles/r01_pmc_fetch_write_default_gauged.txt
-        elif (precision, N, args.ndiv, vel, world) == ("f16x3", 512, 4, True, 1) and dom["kernel"].startswith("conv_h3<FLAT3,vel,dx"):
-            if plan.startswith("(1, 1, 1)") and os.environ.get("NBE_PERIODIC", "1") != "0":
-                traffic = 59.6e9            # profiles/r01_pmc_fetch_write_default_periodic.txt
-            elif plan.startswith("(1, 1, 1)"):
-                traffic = 69.5e9            # profiles/r01_pmc_fetch_write_default_onetile.txt
-            elif plan.startswith("(2, 1, 1)"):
-                traffic = 89.0e9            # profiles/r01_pmc_fetch_write_default_tiles211.txt
-            elif plan.startswith("(2, 2, 2)"):
-                traffic = 26.25e9           # profiles/r01_pmc_fetch_write_default_q16.txt
+        try:
+            from jax_nbody_emulator_with_dj_amd import _lib
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            wl = traffic_key(precision, plan)
+            sub = {"conv_h3g": "conv_h3g_kernel<false>", "conv_h3n": "conv_h3g_kernel<true>", "conv_h3<FLAT3": "conv_h3q_kernel",
+                   "conv_mfma_g": "conv_mfma_kernel"}
+            key = next((v for k, v in sub.items() if dom["kernel"].startswith(k)), None)
+            if tj.get("build") == _lib.source_hash() and tj.get("workload") == wl and key and world == 1:
+                traffic = next((v["traffic_bytes"] for k, v in tj["kernels"].items() if key in k), None)
+        except Exception:
+            traffic = None
         return {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": traffic, "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                 "launches": dom["launches"], "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
 
     dt, prof, ok, plan = measure(args.precision, args.warmup, args.steps)
+
+    def measure_host_path(steps):
+        """The reference's call shape (subbox.py:139-219): host NumPy array in, host NumPy arrays out, through the public
+        API -- create_emulator(...).process_box(box, z, Om).  Warm (first call excluded, as README.md:241)."""
+        from jax_nbody_emulator_with_dj_amd import create_emulator, SubboxConfig, models
+        os.environ["NBE_PRECISION"] = args.precision
+        emu = create_emulator(premodulate=False, compute_vel=vel, load_params=False,
+                              processor_config=SubboxConfig(size=size, ndiv=ndiv))
+        emu.params = params
+        emu.processor.params = params
+        models.get_engine(emu.model, local_rank, args.precision).set_max_tile(args.max_tile)
+        box = data.cpu().numpy()                       # pageable host memory, like np.random.randn(...) in README.md:84
+        res = emu.process_box(box, Z, OM, show_progress=False)             # first call: planning, workspace, pinned pool
+        del res
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = emu.process_box(box, Z, OM, show_progress=False)
+        dth = time.perf_counter() - t0
+        r0 = res[0] if vel else res
+        okh = bool(np.isfinite(r0[:, ::64, ::8, ::8]).all())
+        same = None
+        if vel and world == 1:                         # the resident run wrote `disp`: same box, same arithmetic
+            same = bool(np.array_equal(r0[:, 100], disp[:, 100].cpu().numpy()))
+        del res
+        models.release_engines()
+        return {"value": float(N) ** 3 * steps / dth, "unit": "voxels/s", "ms_per_step": 1e3 * dth / steps, "steps": steps,
+                "input": "pageable NumPy float32", "output": "NumPy float32 (pinned pool)", "finite": okh,
+                "equals_resident_result": same}
+
+    host = None
+    if world == 1 and not args.no_host_path:
+        host = measure_host_path(max(1, min(args.steps, 3)))
     strict = None
     if args.precision != "f32" and world == 1 and not args.no_strict:
         strict = measure("f32", 1, 1)             # the strict-float32 MFMA path on the same box, for reference
@@ -219,7 +256,8 @@ def main():
             "config": {"workload": "process_box %d^3 ndiv=(%d,%d,%d) compute_vel=%s StyleNBodyEmulator%sCore, "
                                    "synthetic seeded weights, box resident in HBM" % (N, *ndiv, vel, "Vel" if vel else ""),
                        "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,),
-                       "internal_tiles": plan, "precision": args.precision},
+                       "internal_tiles": plan, "precision": args.precision,
+                       "traffic_key": traffic_key(args.precision, plan)},
             "finite": ok,
         }
         if prof:
@@ -229,6 +267,9 @@ def main():
                               for e in sorted(prof, key=lambda e: -e["ms"])]
         if phases:
             out["phase_cycles_debug_build"] = phases
+        if host is not None:
+            host["vs_resident"] = host["value"] / out["value"]
+            out["host_path"] = host
         if strict is not None:
             sdt, sprof, sok, _ = strict
             out["strict_f32"] = {"value": vox / sdt, "unit": "voxels/s", "ms_per_step": 1e3 * sdt, "steps": 1,

@@ -14,6 +14,7 @@
 #ifndef NBE_H
 #define NBE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -98,7 +99,8 @@ enum { NBE_Q_GAUGE_ACTIVE = 0,     /* 1: the loaded weights run the two-product 
        NBE_Q_PERIODIC_YX = 2,      /* 1: the last plan runs periodic in y and x                                       */
        NBE_Q_PERIODIC_Z = 3,       /* 1: ... and in z                                                                 */
        NBE_Q_RANGE_SHIFT = 4,      /* k of the last call's range shift 2^k                                            */
-       NBE_Q_WORKSPACE_BYTES = 5 };
+       NBE_Q_WORKSPACE_BYTES = 5,
+       NBE_Q_HOST_PIPE = 6 };      /* 1: the last nbe_process_box call ran the pipelined host path (nbe_host_alloc)    */
 int nbe_query(nbe_ctx* ctx, int what, double* out);
 
 /* replaces model.apply's `params` argument for the Style* cores (README.md:155; subbox.py:224-233) */
@@ -129,6 +131,17 @@ int nbe_forward(nbe_ctx* ctx, const void* x, int D, int H, int W, float Dz, floa
 int nbe_process_box(nbe_ctx* ctx, const void* box, const int64_t size[3], const int ndiv[3], const int pad[6],
                     float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
                     nbe_progress_cb cb, void* user);
+
+/* Pinned host memory from a process-wide pool (hipHostMalloc; freed buffers are kept for reuse up to NBE_PINNED_POOL_GB,
+ * default 16).  Host-array calls of nbe_process_box whose OUTPUT arrays come from here are pipelined when the box runs
+ * as one periodic tile (the default plan of a 512^3 box on a free MI355X): the input goes up in z-chunks through pinned
+ * staging buffers filled by host threads while the first slabs run, and every finished output slab is copied out on a
+ * second stream under the kernels of the next -- the reference does gather -> H2D -> compute -> D2H -> paste serially
+ * per sub-box (subbox.py:195-215).  Plain (pageable) host arrays work as before, un-overlapped.  The Python shim
+ * returns NumPy arrays backed by this pool.  nbe_host_trim releases the pooled buffers. */
+void* nbe_host_alloc(size_t bytes);
+int nbe_host_free(void* p);
+int nbe_host_trim(void);
 
 /* The same loop over a sub-set of the sub-boxes of a REGION of a periodic box (multi-GPU sharding: each
  * rank owns a brick).  Sub-boxes tile [origin, origin+region) with `ndiv`; `order`

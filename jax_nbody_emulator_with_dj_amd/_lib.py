@@ -63,6 +63,9 @@ SIGNATURES = {
     "nbe_set_slab": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_set_periodic": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "nbe_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "nbe_host_free": (C.c_int, [C.c_void_p]),
+    "nbe_host_trim": (C.c_int, []),
     "nbe_check_finite": (C.c_int, [C.c_void_p]),
     "nbe_set_input_range": (C.c_int, [C.c_void_p, C.c_float]),
     "nbe_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
@@ -83,6 +86,17 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the kernel / engine sources: identifies what a measurement was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=False):
@@ -117,6 +131,36 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+class _PinnedBlock:
+    """Owner of one pooled pinned buffer: returns it to the library's pool when the last NumPy view is gone."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().nbe_host_free(C.c_void_p(self.ptr))
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """Uninitialised NumPy array in pinned host memory from the library's pool (include/nbe.h, nbe_host_alloc): the GPU
+    copies straight into it, asynchronously.  Falls back to ordinary memory if pinning fails."""
+    import numpy as np
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    ptr = lib().nbe_host_alloc(max(n, 1)) if n >= (1 << 20) else None   # small arrays are not worth a pinned block
+    if not ptr:
+        return np.empty(shape, dtype)
+    blk = _PinnedBlock(int(ptr), n)
+    buf = (C.c_char * n).from_address(int(ptr))
+    buf._nbe_block = blk                       # the ctypes view (kept alive by the array's buffer) keeps the block alive
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def check(rc):

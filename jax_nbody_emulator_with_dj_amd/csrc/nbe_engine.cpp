@@ -5,14 +5,19 @@
 #include "../../include/nbe.h"
 #include "nbe_kernels.h"
 
+#include <sched.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace nbe;
@@ -75,6 +80,7 @@ struct Layer {
     float *weight = nullptr, *sw = nullptr, *sb = nullptr;   // raw style parameters (device)
     float *wn = nullptr, *dwn = nullptr;          // modulated OIDHW (device)
     PackedW pw;
+    PackedW pwn;                                  // narrow (16-cout tile) packing of w for the gauged 3x3x3 kernel: cout <= 16
     // tangent gauge (style path, see conv_h3g_kernel): dw = w_n (.) (alpha[ci] + beta[co])
     float* bias0 = nullptr;                       // the bias as loaded (device, padded like pw.bias, which holds bias0 * act_scale)
     float *alpha = nullptr, *beta = nullptr;      // this layer's own factors (device; cin / cout entries, zero-padded)
@@ -124,6 +130,27 @@ struct nbe_ctx {
     // device-resident boxes of process_box
     float* box_in = nullptr; int64_t box_in_bytes = 0;
     char* box_out = nullptr; int64_t box_out_bytes = 0;
+    // Host-array calls of process_box (the reference's call shape, subbox.py:168-170, :195-215), pipelined: the input
+    // box goes up in z-chunks through pinned staging buffers while the encoder slabs run, every finished output slab
+    // comes down on a copy stream under the next slab's kernels (HostPipe, below)
+    struct HostPipe {
+        bool active = false, out_async = false;
+        const float* hbox = nullptr;              // caller's (C, S0, S1, S2) array
+        bool in_pinned = false;
+        int C = 0, S0 = 0, S1 = 0, S2 = 0, o0 = 0;    // o0: box plane of tile plane 0 (may be negative: periodic)
+        std::vector<char> up;                     // box plane uploaded?
+        int gz = 0;                               // tile planes [.., gz) have been gathered
+        char *hdisp = nullptr, *hvel = nullptr;   // caller's output arrays (pinned)
+        char *ddisp = nullptr, *dvel = nullptr;   // device staging of the outputs
+        int esz = 4, O0 = 0, O1 = 0, O2 = 0;
+        int nstage = 0;                           // chunks staged so far (ring position)
+    } pipe;
+    bool last_piped = false;                      // the last process_box / process_region call ran pipelined
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    static constexpr int NSTAGE = 3;
+    char* stage_buf[NSTAGE] = {nullptr, nullptr, nullptr}; int64_t stage_bytes = 0;
+    hipEvent_t stage_free[NSTAGE] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_up = nullptr, ev_down = nullptr;
     // profiling
     bool prof = false;
     std::vector<ProfEntry> prof_entries;
@@ -169,6 +196,67 @@ extern "C" double nbe_vel_norm(double z, double Om) {
 // helpers
 // ------------------------------------------------------------------------------------------------
 static int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- host-side helpers of the pipelined host path -------------------------------------------------------------
+static int host_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("NBE_HOST_THREADS")) return std::max(1, atoi(e));
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t set;                                          // the cores this process may actually use
+        if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min<unsigned>(hw ? hw : 64, (unsigned)CPU_COUNT(&set));
+        return (int)std::max(1u, std::min(hw ? hw : 4u, 16u));
+    }();
+    return n;
+}
+template <typename F>
+static void parallel_for(int nt, F&& fn) {                      // fn(i, nt) on nt threads (the caller runs share 0)
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; ++i) th.emplace_back([&fn, i, nt] { fn(i, nt); });
+    fn(0, nt);
+    for (auto& t : th) t.join();
+}
+static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    const int nt = bytes < (size_t(8) << 20) ? 1 : host_threads();
+    parallel_for(nt, [&](int i, int n) {
+        const size_t per = ((bytes + n - 1) / n + 4095) & ~size_t(4095), b = std::min(bytes, per * i), e = std::min(bytes, b + per);
+        if (e > b) memcpy((char*)dst + b, (const char*)src + b, e - b);
+    });
+}
+// bit pattern of max |x| over a host array (the host-side twin of launch_absmax)
+static unsigned host_absmax_bits(const float* x, int64_t n) {
+    const int nt = n < (1 << 22) ? 1 : host_threads();
+    std::vector<unsigned> part(nt, 0u);
+    parallel_for(nt, [&](int i, int k) {
+        const int64_t per = (n + k - 1) / k, b = std::min(n, per * i), e = std::min(n, b + per);
+        const unsigned* u = (const unsigned*)x;
+        unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        int64_t j = b;
+        for (; j + 4 <= e; j += 4) {
+            m0 = std::max(m0, u[j] & 0x7fffffffu); m1 = std::max(m1, u[j + 1] & 0x7fffffffu);
+            m2 = std::max(m2, u[j + 2] & 0x7fffffffu); m3 = std::max(m3, u[j + 3] & 0x7fffffffu);
+        }
+        for (; j < e; ++j) m0 = std::max(m0, u[j] & 0x7fffffffu);
+        part[i] = std::max(std::max(m0, m1), std::max(m2, m3));
+    });
+    unsigned m = 0;
+    for (unsigned v : part) m = std::max(m, v);
+    return m;
+}
+static bool is_pinned_host_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// ---- pinned host memory pool (nbe_host_alloc / nbe_host_free) ---------------------------------------------------
+static std::mutex g_pin_mu;
+static std::multimap<size_t, void*> g_pin_free;                 // size -> buffer, ready for reuse
+static std::map<void*, size_t> g_pin_live;                      // handed out
+static size_t g_pin_free_bytes = 0;
+static size_t pin_pool_cap() {
+    static const size_t cap = (size_t)((getenv("NBE_PINNED_POOL_GB") ? atof(getenv("NBE_PINNED_POOL_GB")) : 16.0) * (1ull << 30));
+    return cap;
+}
 // every consumer reads whole 16-channel chunks; PREC_F16 stores 8 channels per plane, the others 4 (or hi+lo of 8)
 static int planes_for(int C, int prec) { return roundup(C, 16) / (prec == PREC_F16 ? 8 : 4); }
 
@@ -200,6 +288,15 @@ struct Tensor { Planes p; int64_t off = -1; int pad = 0; };
 static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
     Tensor t;
     t.p = ws_planes(c, planes_for(C, c->prec), D, H, W, &t.off);
+    // Channel planes beyond C (C not a multiple of 16: narrow test models) are read by the consumer against zero
+    // weights but never written by the producer: they must hold finite values whatever an earlier call -- another
+    // shape, a NaN in its input, an overflow -- left at this place of the arena.  No such planes at production width.
+    const int gw = c->prec == PREC_F16 ? (C + 7) / 8 : c->prec == PREC_F16X3 ? 2 * ((C + 7) / 8) : (C + 3) / 4;
+    if (!c->dry && t.off >= 0 && gw < t.p.G) {
+        const size_t off = (size_t)gw * t.p.pstride * 4, bytes = (size_t)(t.p.G - gw) * t.p.pstride * 16;
+        (void)hipMemsetAsync(t.p.x + off, 0, bytes, c->stream);
+        if (t.p.dx) (void)hipMemsetAsync(t.p.dx + off, 0, bytes, c->stream);
+    }
     return t;
 }
 // interior Hi x Wi plus a y/x halo of `pad`
@@ -255,7 +352,7 @@ static void prof_collect(nbe_ctx* c) {
 static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false) {
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
     char b[96];
-    if (g6 && prec_is_half(pw.prec)) snprintf(b, sizeof b, "%s<%s,vel,dx>", pw.prec == PREC_F16 ? "conv_h1g" : "conv_h3g", m);
+    if (g6 && prec_is_half(pw.prec)) snprintf(b, sizeof b, "%s<%s,vel,dx>", pw.prec == PREC_F16 ? "conv_h1g" : (pw.cout_t == 16 ? "conv_h3n" : "conv_h3g"), m);
     else if (g6) snprintf(b, sizeof b, "conv_mfma_g<%s,vel,dx,ni%d>", m, pw.ni);
     else if (prec_is_half(pw.prec))
         snprintf(b, sizeof b, "%s<%s,%s,%s>", pw.prec == PREC_F16 ? "conv_h1" : "conv_h3", m, vel ? "vel" : "novel", (vel && has_dx) ? "dx" : "nodx");
@@ -273,13 +370,15 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
     cl.flags |= dbgf;
     const bool g6 = c->gauge_active && L.g6 && has_dx;
     if (c->gauge_active) { cl.gout = L.gout; cl.beta = g6 ? L.beta : nullptr; }
+    static const bool no_narrow = getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0;      // A/B switch
+    const PackedW& pw = (g6 && L.pwn.w && !no_narrow) ? L.pwn : L.pw;
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
-        pe = prof_entry(c, conv_name(L.pw, c->vel, has_dx, g6));
+        pe = prof_entry(c, conv_name(pw, c->vel, has_dx, g6));
         ea = get_event(c); eb = get_event(c);
         (void)hipEventRecord(ea, c->stream);
     }
-    if (launch_conv(L.pw, cl, c->vel, has_dx, c->stream))
+    if (launch_conv(pw, cl, c->vel, has_dx, c->stream))
         return fail("internal error: no kernel for layer %s/%s (mode %d, gauged %d, input tangent %d, crop offset %ld, output stride %d)",
                     L.block.c_str(), L.layer.c_str(), L.pw.mode, (int)g6, (int)has_dx, (long)cl.in_off, cl.osz);
     if (c->prof) {
@@ -498,13 +597,16 @@ static void run_head(nbe_ctx* c, const Tensor& y, const Tensor& xin, const HeadO
 // power of two.  The f16-based modes use that to keep their operands where f16 has both range and precision: s = 2^k
 // brings max(|x| Dz / 6, max |b|) into [0.5, 1) whatever the caller's units are.
 // ------------------------------------------------------------------------------------------------
-static int prepare_range(nbe_ctx* c, const float* dev_src, int64_t n, float Dz) {
+static int prepare_range(nbe_ctx* c, const float* dev_src, int64_t n, float Dz, const float* host_src = nullptr) {
     c->input_finite = true;
     float s = 1.f;
     if (prec_is_half(c->prec)) {
         if (!c->flags) { HIPCHK(hipMalloc((void**)&c->flags, 8)); HIPCHK(hipMemsetAsync(c->flags, 0, 8, c->stream)); }
         float amax = c->preset_absmax;
-        if (amax < 0.f) {
+        if (amax < 0.f && host_src) {                           // pipelined host path: the box is not on the device yet
+            const unsigned bits = host_absmax_bits(host_src, n);
+            memcpy(&amax, &bits, 4);
+        } else if (amax < 0.f) {
             HIPCHK(hipMemsetAsync(c->flags, 0, 4, c->stream));
             launch_absmax(dev_src, n, c->flags, c->stream);
             unsigned bits = 0;
@@ -548,6 +650,82 @@ static int check_range(nbe_ctx* c) {
              "(|value| >= 65504 * 2^%d after the range shift); rerun this call with NBE_PREC_F32",
              c->prec == PREC_F16 ? "float16" : "f16x3", -(int)std::lround(std::log2(c->act_scale)));
         return 2;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined host path (HostPipe).  The tile is the whole periodic box; tile plane t is box plane (o0 + t) mod S0.
+// ------------------------------------------------------------------------------------------------
+static constexpr int PIPE_CHUNK = 32;                            // box planes per staged upload
+
+// box planes behind tile planes [t0, t1) -> device box (enqueued on up_stream; pageable sources go through the pinned
+// staging ring, filled by host threads)
+static int pipe_upload(nbe_ctx* c, int t0, int t1) {
+    auto& P = c->pipe;
+    const int64_t plane = (int64_t)P.S1 * P.S2;
+    const int D = P.S0 + 96;
+    t0 = std::max(t0, 0); t1 = std::min(t1, D);
+    int t = t0;
+    while (t < t1) {
+        const int b = ((P.o0 + t) % P.S0 + P.S0) % P.S0;
+        if (P.up[b]) { ++t; continue; }
+        int run = 1;
+        while (t + run < t1 && b + run < P.S0 && !P.up[b + run] && run < PIPE_CHUNK) ++run;
+        const size_t bytes = (size_t)run * plane * 4;            // per channel
+        float* dbox = c->box_in;
+        if (P.in_pinned) {
+            for (int ch = 0; ch < P.C; ++ch)
+                HIPCHK(hipMemcpyAsync(dbox + ((int64_t)ch * P.S0 + b) * plane, P.hbox + ((int64_t)ch * P.S0 + b) * plane,
+                                      bytes, hipMemcpyHostToDevice, c->up_stream));
+        } else {
+            const int slot = P.nstage % nbe_ctx::NSTAGE;
+            if (P.nstage >= nbe_ctx::NSTAGE) HIPCHK(hipEventSynchronize(c->stage_free[slot]));   // its last DMA has finished
+            for (int ch = 0; ch < P.C; ++ch)
+                parallel_memcpy(c->stage_buf[slot] + ch * bytes, P.hbox + ((int64_t)ch * P.S0 + b) * plane, bytes);
+            for (int ch = 0; ch < P.C; ++ch)
+                HIPCHK(hipMemcpyAsync(dbox + ((int64_t)ch * P.S0 + b) * plane, c->stage_buf[slot] + ch * bytes, bytes,
+                                      hipMemcpyHostToDevice, c->up_stream));
+            HIPCHK(hipEventRecord(c->stage_free[slot], c->up_stream));
+            ++P.nstage;
+        }
+        for (int k = 0; k < run; ++k) P.up[b + k] = 1;
+        t += run;
+    }
+    return 0;
+}
+
+// tile planes [t0, t1) of the input tensor: upload what is missing, gather them (core :132-134 scaling), then start the
+// upload of the `look` planes that follow so that it runs under the kernels enqueued next
+static int pipe_input(nbe_ctx* c, const Tensor& tin, int t0, int t1, int look, float scale) {
+    auto& P = c->pipe;
+    if (P.gz < t0) P.gz = t0;                                    // planes before t0 are never read
+    if (t1 > P.gz) {
+        if (pipe_upload(c, P.gz, t1)) return 1;
+        HIPCHK(hipEventRecord(c->ev_up, c->up_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_up, 0));
+        const Tensor v = zview(tin, P.gz, t1 - P.gz);
+        const int h = tin.pad ? 1 : 48;
+        launch_gather(c->box_in, P.C, P.S0, P.S1, P.S2, P.o0 + P.gz, -h, -h, v.p, scale, c->prec, c->stream);
+        P.gz = t1;
+    }
+    return look > 0 ? pipe_upload(c, t1, t1 + look) : 0;
+}
+
+// output planes [z, z + n) of every channel of both fields: device staging -> the caller's pinned arrays, on the
+// down stream, behind the head launch that produced them
+static int pipe_output(nbe_ctx* c, int z, int n) {
+    auto& P = c->pipe;
+    HIPCHK(hipEventRecord(c->ev_down, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->down_stream, c->ev_down, 0));
+    const int64_t plane = (int64_t)P.O1 * P.O2 * P.esz;
+    for (int f = 0; f < (P.hvel ? 2 : 1); ++f) {
+        char* h = f ? P.hvel : P.hdisp;
+        const char* d = f ? P.dvel : P.ddisp;
+        for (int ch = 0; ch < c->out_chan; ++ch) {
+            const int64_t off = ((int64_t)ch * P.O0 + z) * plane;
+            HIPCHK(hipMemcpyAsync(h + off, d + off, (size_t)n * plane, hipMemcpyDeviceToHost, c->down_stream));
+        }
     }
     return 0;
 }
@@ -596,6 +774,7 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
         const bool first = z == zlo;
         // periodic in z: the slab is exactly planes [z - 40, z - 40 + n) of the skip connection -- write it there
         const Tensor y0 = pz ? zview(skip0, z - 40, n) : zview(y0r, 0, n);
+        if (c->pipe.active && !c->dry && pipe_input(c, tin, z, z + n + 8, S, ho.Dz / 6.0f * c->act_scale)) return 1;
         if (first) {
             if (resblock_part(c, "conv_l00", zview(tin, z, n + 8), h0, a, 0, n + 4, 0, n + 6, false, true)) return 1;
             if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 0, n + 2, true, true)) return 1;
@@ -715,6 +894,7 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
             carry_planes(c, hy, n, 0, 2);
         }
         run_head(c, zview(y, 0, n), zview(tin, z, n + 96), ho, z);
+        if (c->pipe.active && c->pipe.out_async && !c->dry && pipe_output(c, z, n)) return 1;
         if (c->prog_cb && !c->dry && z + n < Yo) {               // the tile's last slab is reported by the sub-box loop
             (void)hipStreamSynchronize(c->stream);
             c->prog_cb(c->prog_k * 1000 + (int)(1000L * (z + n) / Yo), c->prog_n * 1000, c->prog_user);
@@ -775,8 +955,9 @@ static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int 
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
     tin.pad = c->pyx ? 1 : 0;                                   // periodic-yx: (H, W) = box extent + 2, gathered from origin - 1
-    // core :132-134: x = x * (Dz / 6)
-    launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
+    // core :132-134: x = x * (Dz / 6); the pipelined host path gathers slab by slab as the box arrives (pipe_input)
+    if (!c->pipe.active)
+        launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
     const HeadOut ho{disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, Dz, vel_fac};
     if (c->slab > 0) return network_stream(c, tin, ho, c->slab);
     if (network(c, tin, &y)) return 1;
@@ -791,7 +972,7 @@ static void free_layers(nbe_ctx* c) {
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
-        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0);
+        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pwn.w);
         (void)hipFree(L.alpha); (void)hipFree(L.beta);
     }
     c->layers.clear();
@@ -1000,6 +1181,13 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
         HIPCHK(hipMalloc((void**)&pw.bias, nb * 4));
         HIPCHK(hipMemset(pw.bias, 0, nb * 4));
         HIPCHK(hipMemcpy(pw.bias, d.bias, d.cout * 4, hipMemcpyHostToDevice));
+        if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && d.cout <= 16 && !L.first) {
+            PackedW& pn = L.pwn;                               // same layer, 16-cout tiles (conv_h3g_kernel<true>)
+            pn = pw; pn.w = nullptr; pn.dw = nullptr;
+            pn.cout_t = 16; pn.ctiles = 1;
+            pn.floats = (int64_t)16 * mode_nseg(pn.mode) * mode_taps(pn.mode) * pn.cin_pad;
+            HIPCHK(hipMalloc((void**)&pn.w, pn.floats * 4));
+        }
         HIPCHK(hipMalloc((void**)&L.bias0, nb * 4));
         HIPCHK(hipMemcpy(L.bias0, pw.bias, nb * 4, hipMemcpyDeviceToDevice));
         for (int i = 0; i < d.cout; ++i)
@@ -1020,6 +1208,7 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             if (c->vel) HIPCHK(hipMemcpy(L.dwn, d.dweight, nw * 4, hipMemcpyHostToDevice));
             launch_pack(L.wn, d.cout, d.cin, L.kind, pw, pw.w, c->stream);
             if (c->vel) launch_pack(L.dwn, d.cout, d.cin, L.kind, pw, pw.dw, c->stream);
+            if (L.pwn.w) launch_pack(L.wn, d.cout, d.cin, L.kind, L.pwn, L.pwn.w, c->stream);
         }
         c->layers[L.block + "/" + L.layer] = L;
     }
@@ -1076,6 +1265,11 @@ int nbe_destroy(nbe_ctx* c) {
     free_layers(c);
     (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag); (void)hipFree(c->flags);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < nbe_ctx::NSTAGE; ++i) { if (c->stage_buf[i]) (void)hipHostFree(c->stage_buf[i]); if (c->stage_free[i]) (void)hipEventDestroy(c->stage_free[i]); }
+    if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+    if (c->ev_down) (void)hipEventDestroy(c->ev_down);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -1149,6 +1343,7 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
         launch_modulate(L.weight, L.sw, L.sb, L.cout, L.cin, L.k * L.k * L.k, s0, s1, c->eps, L.first ? 1 : 0,
                         L.wn, c->vel ? L.dwn : nullptr, c->stream, use_gauge ? L.a_in : nullptr, use_gauge ? L.beta : nullptr);
         launch_pack(L.wn, L.cout, L.cin, L.kind, L.pw, L.pw.w, c->stream);
+        if (L.pwn.w) launch_pack(L.wn, L.cout, L.cin, L.kind, L.pwn, L.pwn.w, c->stream);
         if (c->vel && !(use_gauge && L.g6)) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pw, L.pw.dw, c->stream);
     }
     c->gauge_active = use_gauge;
@@ -1427,10 +1622,47 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     const bool in_dev = is_device_ptr(box), out_dev = is_device_ptr(disp);
     if (ensure_workspace(c, D, H, W)) return 1;
     const float* bd = (const float*)box;
+    // Host arrays in and out, the whole periodic box as one tile in the z-slab schedule, pinned outputs: pipelined
+    // (HostPipe).  Anything else: the box goes up in one piece before the first tile and the fields come down after the last.
+    static const bool pipe_off = getenv("NBE_HOST_PIPE") && atoi(getenv("NBE_HOST_PIPE")) == 0;
+    auto& P = c->pipe;
+    P.active = false;
+    if (!in_dev && !out_dev && !order && !pipe_off && c->slab > 0 && c->pyx && c->pz && ndiv[0] * ndiv[1] * ndiv[2] == 1 &&
+        !cb && S0 == O0 && S1 == O1 && S2 == O2 && oorigin[0] == 0 && oorigin[1] == 0 && oorigin[2] == 0) {
+        P.active = true;
+        P.hbox = (const float*)box; P.in_pinned = is_pinned_host_ptr(box);
+        P.C = c->in_chan; P.S0 = S0; P.S1 = S1; P.S2 = S2; P.o0 = (int)origin[0] - 48;
+        P.up.assign(S0, 0); P.gz = 0; P.nstage = 0;
+        P.out_async = is_pinned_host_ptr(disp) && (!c->vel || is_pinned_host_ptr(vel));
+        P.hdisp = (char*)disp; P.hvel = c->vel ? (char*)vel : nullptr; P.esz = esz; P.O0 = O0; P.O1 = O1; P.O2 = O2;
+        if (!c->up_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_down, hipEventDisableTiming));
+            for (int i = 0; i < nbe_ctx::NSTAGE; ++i) HIPCHK(hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming));
+        }
+        const int64_t sb = (int64_t)PIPE_CHUNK * S1 * S2 * 4 * c->in_chan;
+        if (!P.in_pinned && sb > c->stage_bytes) {
+            for (int i = 0; i < nbe_ctx::NSTAGE; ++i) {
+                if (c->stage_buf[i]) (void)hipHostFree(c->stage_buf[i]);
+                c->stage_buf[i] = nullptr;
+                HIPCHK(hipHostMalloc((void**)&c->stage_buf[i], sb, hipHostMallocDefault));
+            }
+            c->stage_bytes = sb;
+        }
+    }
+    struct PipeGuard { nbe_ctx::HostPipe& p; ~PipeGuard() { p.active = false; } } pipe_guard{P};
+    c->last_piped = P.active;
     if (!in_dev) {
         if (in_bytes > c->box_in_bytes) { (void)hipFree(c->box_in); c->box_in = nullptr; c->box_in_bytes = 0;
                                           HIPCHK(hipMalloc((void**)&c->box_in, in_bytes)); c->box_in_bytes = in_bytes; }
-        HIPCHK(hipMemcpyAsync(c->box_in, box, in_bytes, hipMemcpyHostToDevice, c->stream));
+        if (P.active) {
+            // whatever still reads the device box from the previous call must have finished before the uploads start
+            HIPCHK(hipStreamSynchronize(c->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(c->box_in, box, in_bytes, hipMemcpyHostToDevice, c->stream));
+        }
         bd = c->box_in;
     }
     char *dd = (char*)disp, *vd = (char*)vel;
@@ -1439,13 +1671,19 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         if (need > c->box_out_bytes) { (void)hipFree(c->box_out); c->box_out = nullptr; c->box_out_bytes = 0;
                                        HIPCHK(hipMalloc((void**)&c->box_out, need)); c->box_out_bytes = need; }
         dd = c->box_out; vd = c->box_out + out_bytes;
+        P.ddisp = dd; P.dvel = c->vel ? vd : nullptr;
     }
-    // subbox.py:168-170: outputs start as zeros (voxels beyond ndiv*crop_size stay zero)
-    if (zero_out || !out_dev) {
+    // subbox.py:168-170: outputs start as zeros (voxels beyond ndiv*crop_size stay zero); the one-tile plan of the
+    // pipelined path writes every voxel
+    if ((zero_out || !out_dev) && !P.active) {
         HIPCHK(hipMemsetAsync(dd, 0, out_bytes, c->stream));
         if (c->vel) HIPCHK(hipMemsetAsync(vd, 0, out_bytes, c->stream));
     }
-    if (prepare_range(c, bd, (int64_t)c->in_chan * S0 * S1 * S2, Dz)) return 1;
+    if (P.active) {
+        // start the first upload, then reduce max|x| on the host while the DMA runs
+        if (pipe_upload(c, 40, 40 + c->slab + 8)) return 1;
+        if (prepare_range(c, nullptr, (int64_t)c->in_chan * S0 * S1 * S2, Dz, (const float*)box)) return 1;
+    } else if (prepare_range(c, bd, (int64_t)c->in_chan * S0 * S1 * S2, Dz)) return 1;
     const int total = ndiv[0] * ndiv[1] * ndiv[2];
     const int n = order ? norder : total;
     for (int k = 0; k < n; ++k) {
@@ -1461,11 +1699,12 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     }
     c->prog_cb = nullptr;
     HIPCHK(hipGetLastError());
-    if (!out_dev) {
+    if (!out_dev && !(P.active && P.out_async)) {
         HIPCHK(hipMemcpyAsync(disp, dd, out_bytes, hipMemcpyDeviceToHost, c->stream));
         if (c->vel) HIPCHK(hipMemcpyAsync(vel, vd, out_bytes, hipMemcpyDeviceToHost, c->stream));
     }
     if (!out_dev || !in_dev) {
+        if (P.active) { HIPCHK(hipStreamSynchronize(c->up_stream)); HIPCHK(hipStreamSynchronize(c->down_stream)); }
         HIPCHK(hipStreamSynchronize(c->stream));
         return check_range(c);                                  // host arrays: the call is synchronous anyway
     }
@@ -1491,6 +1730,45 @@ int nbe_process_region(nbe_ctx* c, const void* box, const int64_t box_size[3], c
                           out_size, out_origin, false, nullptr, nullptr);
 }
 
+void* nbe_host_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_free.lower_bound(bytes);
+        if (it != g_pin_free.end() && it->first <= bytes + bytes / 8) {      // close enough in size: reuse
+            void* p = it->second; const size_t sz = it->first;
+            g_pin_free.erase(it); g_pin_free_bytes -= sz; g_pin_live[p] = sz;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail("nbe_host_alloc: hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_live[p] = bytes;
+    return p;
+}
+
+int nbe_host_free(void* p) {
+    if (!p) return 0;
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_live.find(p);
+        if (it == g_pin_live.end()) return fail("nbe_host_free: %p was not allocated by nbe_host_alloc", p);
+        sz = it->second; g_pin_live.erase(it);
+        if (g_pin_free_bytes + sz <= pin_pool_cap()) { g_pin_free.emplace(sz, p); g_pin_free_bytes += sz; return 0; }
+    }
+    (void)hipHostFree(p);
+    return 0;
+}
+
+int nbe_host_trim(void) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto& kv : g_pin_free) (void)hipHostFree(kv.second);
+    g_pin_free.clear(); g_pin_free_bytes = 0;
+    return 0;
+}
+
 int nbe_check_finite(nbe_ctx* c) {
     if (!c) return fail("null context");
     HIPCHK(hipSetDevice(c->device));
@@ -1512,6 +1790,7 @@ int nbe_query(nbe_ctx* c, int what, double* out) {
     case NBE_Q_PERIODIC_Z: *out = c->pz ? 1 : 0; break;
     case NBE_Q_RANGE_SHIFT: *out = std::log2((double)c->act_scale); break;
     case NBE_Q_WORKSPACE_BYTES: *out = (double)c->ws_bytes; break;
+    case NBE_Q_HOST_PIPE: *out = c->last_piped ? 1 : 0; break;
     default: return fail("nbe_query: unknown item %d", what);
     }
     return 0;

@@ -51,6 +51,7 @@ struct PackedW {
     float* bias = nullptr;   // padded to ct*COUT_T
     int prec = PREC_F32;
     int mode = 0, ni = 2;    // COUT_T = 32*ni (PREC_F16X3: always 64)
+    int cout_t = 64;         // f16-based packing: couts per tile; 16 = the narrow tile of conv_h3g_kernel<true>
     int cin = 0, cout = 0;   // logical channels
     int cin_pad = 0;         // multiple of CK
     int ctiles = 0;          // cout tiles

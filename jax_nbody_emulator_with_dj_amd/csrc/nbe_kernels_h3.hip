@@ -1033,10 +1033,31 @@ static int launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
 // Without dW a whole (chunk, dz) group of weights is 36 KB: weights AND patches are double-buffered by group
 // (2 x 36 KB + 2 x 44 KB = the same 160 KB), every DMA is issued a full group (~2 us) ahead of its use, and a group
 // ends with ONE barrier.  Operand layout, tap pairing, MFMA shape and the wave tile are those of conv_h3q_kernel.
-constexpr int HG_WG = 9 * HQ_TAPU;                         // units of one group's weights (set w)
-static_assert(2 * HG_WG == HQ_XBASE, "the two weight buffers fill exactly what conv_h3q_kernel uses for four");
+//
+// NARROW: the same kernel for layers with at most 16 output channels (conv_r01/conv_1, 64 -> 3: a full-resolution
+// layer that the 64-cout tile computes at 64 / 3 times its cost -- 9 % of the wide kernel's time per box).  One
+// 16-cout MFMA row tile; wave w owns row w of the 8 x 32 patch (two column tiles); weight rows are 16 couts wide
+// ([group][tap][unit][16 couts][8 ch], packed with cout_t = 16), a group of weights is 9 KB.  Each activation operand
+// then feeds one MFMA instead of two and the patch DMA is spread over a quarter of the MFMAs: the variant is bound by
+// the L2 -> LDS stream (about 2650 cycles per group against 1800 of MFMA), i.e. ~3.8 x faster than the wide tile.
+template <bool NARROW>
+struct HGGeom {
+    static constexpr int CT = NARROW ? 16 : 64;             // couts per tile = rows of one weight unit in LDS
+    static constexpr int TAPU = 4 * CT;                     // 16-byte units per tap
+    static constexpr int WG = 9 * TAPU;                     // units of one group's weights (set w)
+    static constexpr int XBASE = 2 * WG;                    // the two patch buffers follow the two weight buffers
+    static constexpr int LDS_UNITS = XBASE + 2 * HQ_XB;
+    static constexpr int MT = NARROW ? 1 : 2, NT = NARROW ? 2 : 4, NTILE = MT * NT;   // MFMA tiles of a wave
+    static constexpr int NWI = WG / 64;                     // weight DMA wave-instructions per group: 36 / 9
+    static constexpr int NWS = (NWI + 7) / 8;               // ... slots per wave: 5 / 2
+};
+static_assert(HGGeom<false>::XBASE == HQ_XBASE, "the two weight buffers fill exactly what conv_h3q_kernel uses for four");
 
+template <bool NARROW>
 __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
+    typedef HGGeom<NARROW> G;
+    constexpr int CT = G::CT, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = G::MT, NT = G::NT, NTILE = G::NTILE;
+    constexpr int NWS = G::NWS;
 #if NBE_DBG   // phases as h3q_stamps: 0 prologue, 1 group up to its barrier, 2 own DMA, 3 barrier, 4 the three products after it, 7 epilogue
     unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define NBE_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[i] += t_ - tk0; tk0 = t_; }
@@ -1053,7 +1074,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 
     // cout tile fastest, then z (as in conv_h3q_kernel): the workgroups of one patch that differ only in their 64 couts
     // run side by side on one XCD and share the patch through its L2 instead of fetching it from HBM once per cout tile
-    const int nct = (a.cout_groups + 7) / 8;
+    const int nct = (a.cout_groups + CT / 8 - 1) / (CT / 8);
     const int vt = xcd_tile(blockIdx.x, a.ntiles * nct);
     const int tile = vt / nct, ct = vt - tile * nct;
     const int z = tile % a.Dv, tyx = tile / a.Dv;
@@ -1064,11 +1085,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     const unsigned lane16 = (unsigned)lane * 16u;
     // ---- DMA of group g into buffers g & 1: 36 wave-instructions of weights (5 slots per wave), 24 + 24 of the
     // x and dx~ patches (3 + 3 slots per wave)
-    const long wct = (long)ct * ngroups * HG_WG;
+    const long wct = (long)ct * ngroups * WGU;
     auto dma_w = [&](int g, int t) {
         const int n = wave + 8 * t;
-        if (n >= HG_WG / 64) return;
-        dma16s((const char*)a.w + (wct + (long)g * HG_WG + n * 64) * 16, lane16, lds + (g & 1) * HG_WG + n * 64);
+        if (n >= G::NWI) return;
+        dma16s((const char*)a.w + (wct + (long)g * WGU + n * 64) * 16, lane16, lds + (g & 1) * WGU + n * 64);
     };
     unsigned xoff[3];
     bool xval[3];
@@ -1089,53 +1110,59 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         const int n = wave + 8 * t, pl = n / 6, k = n - 6 * pl;
         if (xval[t])
             dma16s((const char*)(tensor ? a.dx : a.x) + xo + (long)pl * a.in_pstride * 16, xoff[t],
-                   lds + HQ_XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HQ_PP + k * 64);
+                   lds + XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HQ_PP + k * 64);
     };
-    auto dma_slot = [&](int k, int g, long xo) {                 // slot k of the 11 of group g
-        if (k < 5) dma_w(g, k);
-        else if (k < 8) dma_x(0, k - 5, xo, g & 1);
-        else if (k < 11) dma_x(1, k - 8, xo, g & 1);
+    auto dma_slot = [&](int k, int g, long xo) {                 // slot k of the NWS + 6 (11 / 8) of group g
+        if (k < NWS) dma_w(g, k);
+        else if (k < NWS + 3) dma_x(0, k - NWS, xo, g & 1);
+        else if (k < NWS + 6) dma_x(1, k - NWS - 3, xo, g & 1);
     };
 
-    f32x4 ym[8], yc[8], dm[8], dc[8];                            // AGPRs, updated in place (see conv_h3q_kernel)
+    f32x4 ym[NTILE], yc[NTILE], dm[NTILE], dc[NTILE];            // AGPRs, updated in place (see conv_h3q_kernel)
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < NTILE; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ym[t][e] = 0.f; yc[t][e] = 0.f; dm[t][e] = 0.f; dc[t][e] = 0.f; }
     auto mm = [&](f32x4& acc, const half8& A, const half8& B) {
         asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
     };
 
-    const int aP = (ks * 4 + 2 * kh) * 64 + 32 * it + c;
-    const int bB = (2 * kh) * HQ_PP + (2 * jq) * HP_RS + c;
+    const int rowc = NARROW ? 0 : 32 * it;                       // first cout row of this wave inside the tile
+    const int rowp = NARROW ? wave : 2 * jq;                     // first patch row of this wave
+    const int aP = (ks * 4 + 2 * kh) * CT + rowc + c;
+    const int bB = (2 * kh) * HQ_PP + rowp * HP_RS + c;
     const int bP1 = bB + ks, bP32 = bB + 32 * ks;
-    auto LA = [&](half8 (&r)[2], int idx) {
+    auto LA = [&](half8 (&r)[MT], int idx) {
         r[0] = L8[idx];
-        r[1] = L8[idx + 16];
+        if (MT == 2) r[MT - 1] = L8[idx + 16];
     };
-    auto LB = [&](half8 (&r)[4], int idx) {
+    auto LB = [&](half8 (&r)[NT], int idx) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) r[nt] = L8[idx + (nt >> 1) * HP_RS + 16 * (nt & 1)];
+        for (int nt = 0; nt < NT; ++nt) r[nt] = L8[idx + (NARROW ? 0 : (nt >> 1)) * HP_RS + 16 * (NARROW ? nt : (nt & 1))];
     };
-    // one product on the wave tile: 8 MFMAs; slot >= 0: DMA slots `slot`, `slot + 1` of group gn after the 4th / 8th
-    auto MM8 = [&](f32x4 (&acc)[8], const half8 (&A)[2], const half8 (&B)[4], int slot, int gn, long xo, bool px) {
+    // one product on the wave tile: NTILE MFMAs; slot >= 0: DMA slots `slot`, `slot + 1` of group gn, one after each
+    // MFMA row (wide) or both after the product (narrow)
+    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int gn, long xo, bool px) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            mm(acc[t], A[t >> 2], B[t & 3]);
-            if (slot >= 0 && (t & 3) == 3) {
-                if (px) dma_slot(slot + (t >> 2), gn, xo);
+        for (int t = 0; t < NTILE; ++t) {
+            mm(acc[t], A[t / NT], B[t % NT]);
+            if (slot >= 0 && (t % NT) == NT - 1) {
+                if (px) {
+                    if (MT == 2) dma_slot(slot + t / NT, gn, xo);
+                    else { dma_slot(slot, gn, xo); dma_slot(slot + 1, gn, xo); }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
 #define NBE_SB __builtin_amdgcn_sched_barrier(0)
-    half8 wh[2], wl[2], xh[4], xl[4], dxh[4], dxl[4];
+    half8 wh[MT], wl[MT], xh[NT], xl[NT], dxh[NT], dxl[NT];
     // A tap pair: six products.  On entry wh, xl and xh of the pair are loaded (or in flight); preXl / preW / preXh
     // request those of whatever follows as soon as the registers are free.  Dependent MFMAs are >= 8 MFMAs apart.
     // (mid: after the third product every LDS read of the pair has been issued -- the group's barrier goes there)
     auto pair = [&](int slot0, int gn, long xo, bool px, int wa, int xp, auto&& preXl, auto&& preW, auto&& preXh,
                     auto&& mid) {
-        LA(wl, wa + 64 + aP); LB(dxh, xp + HQ_XT);
+        LA(wl, wa + CT + aP); LB(dxh, xp + HQ_XT);
         NBE_SB; MM8(yc, wh, xl, slot0, gn, xo, px); NBE_SB;
         LB(dxl, xp + HQ_XT + HQ_PP);
         NBE_SB; MM8(ym, wh, xh, slot0 < 0 ? -1 : slot0 + 2, gn, xo, px); NBE_SB;
@@ -1153,48 +1180,48 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     {
         const long x0off = patch_offset(0);
 #pragma unroll
-        for (int k = 0; k < 11; ++k) dma_slot(k, 0, x0off);
+        for (int k = 0; k < NWS + 6; ++k) dma_slot(k, 0, x0off);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         NBE_STAMP(0)
-        LA(wh, aP); LB(xl, HQ_XBASE + bP1 + HQ_PP); LB(xh, HQ_XBASE + bP1);
+        LA(wh, aP); LB(xl, XBASE + bP1 + HQ_PP); LB(xh, XBASE + bP1);
     }
 
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
     for (int g = 0; g < ngroups; ++g) {
         const bool px = g + 1 < ngroups;
         const long xo = px ? patch_offset(g + 1) : 0;
-        const int wb = (g & 1) * HG_WG, xb = HQ_XBASE + (g & 1) * HQ_XB;
-        const int wbn = HG_WG - wb, xbn = HQ_XBASE + ((g + 1) & 1) * HQ_XB;
-        half8 a1w[2], a0[2], b1x[4], b1d[4];
+        const int wb = (g & 1) * WGU, xb = XBASE + (g & 1) * HQ_XB;
+        const int wbn = WGU - wb, xbn = XBASE + ((g + 1) & 1) * HQ_XB;
+        half8 a1w[MT], a0[MT], b1x[NT], b1d[NT];
         // single tap 4 = (dy 1, dx 1): the lane-group halves select the PART: [wh|wl].[xl|xh] and [0|wh].[xl|xh]
-        const int aS1 = wb + 4 * HQ_TAPU + (2 * kh + ks) * 64 + 32 * it + c;
-        const int aS0 = wb + 4 * HQ_TAPU + (2 * kh) * 64 + 32 * it + c;
-        const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + (2 * jq) * HP_RS + c + SH4;
+        const int aS1 = wb + 4 * TAPU + (2 * kh + ks) * CT + rowc + c;
+        const int aS0 = wb + 4 * TAPU + (2 * kh) * CT + rowc + c;
+        const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + rowp * HP_RS + c + SH4;
 
         pair(0, g + 1, xo, px, wb, xb + bP1,                                           // taps (0,1) + the DMA of group g+1
-             [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * HQ_TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
+             [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
              [&] {});
-        pair(-1, g + 1, xo, px, wb + 2 * HQ_TAPU, xb + 2 + bP32,                        // taps (2,3)
+        pair(-1, g + 1, xo, px, wb + 2 * TAPU, xb + 2 + bP32,                        // taps (2,3)
              [&] { LB(b1x, bS1); }, [&] { LA(a1w, aS1); LA(a0, aS0); }, [&] { LB(b1d, bS1 + HQ_XT); }, [&] {});
         {
             const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            a0[0] = ks ? a0[0] : zero;                                   // [0 | wh]
-            a0[1] = ks ? a0[1] : zero;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a0[mt] = ks ? a0[mt] : zero;       // [0 | wh]
         }
         NBE_SB; MM8(yc, a1w, b1x, -1, 0, 0, false); NBE_SB;                  // wh.xl + wl.xh
         LB(xl, xb + SH5 + bP32 + HQ_PP);
         NBE_SB; MM8(ym, a0, b1x, -1, 0, 0, false); NBE_SB;                   // wh.xh
-        LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * HQ_TAPU + aP);
+        LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
         NBE_SB; MM8(dc, a1w, b1d, -1, 0, 0, false); NBE_SB;                  // wh.dxl + wl.dxh
         MM8(dm, a0, b1d, -1, 0, 0, false); NBE_SB;                           // wh.dxh
-        pair(-1, g + 1, xo, px, wb + 5 * HQ_TAPU, xb + SH5 + bP32,                      // taps (5,6)
-             [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * HQ_TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
+        pair(-1, g + 1, xo, px, wb + 5 * TAPU, xb + SH5 + bP32,                      // taps (5,6)
+             [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
              [&] {});
         // taps (7,8).  The group's one barrier sits after the third product: by then this wave has read everything it
         // needs from the buffers of group g, and all of group g+1 has landed once every wave has waited for its own
         // DMA -- the first operands of group g+1 are requested under the last three products.
-        pair(-1, g + 1, xo, px, wb + 7 * HQ_TAPU, xb + SH7 + bP1,
+        pair(-1, g + 1, xo, px, wb + 7 * TAPU, xb + SH7 + bP1,
              [&] { if (px) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (px) LA(wh, wbn + aP); }, [&] { if (px) LB(xh, xbn + bP1); },
              [&] { NBE_STAMP(1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); NBE_STAMP(2)
                    asm volatile("s_barrier" ::: "memory"); NBE_STAMP(3) });
@@ -1206,31 +1233,31 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     // ---- epilogue (layout and load-first order of conv_h3q_kernel): y = W.x + b, dy = W.dx~ + beta * (W.x)
     {
         const bool act = a.flags & F_ACT, res = a.flags & F_RES, gauge = a.gout != nullptr;
-        int unit[2];
-        bool uok[2];
-        f32x4 bv[2], be[2], gv[2];
+        int unit[MT];
+        bool uok[MT];
+        f32x4 bv[MT], be[MT], gv[MT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            unit[mt] = ct * 8 + 4 * it + 2 * mt + ks;
+        for (int mt = 0; mt < MT; ++mt) {
+            unit[mt] = ct * (CT / 8) + (NARROW ? 0 : 4 * it) + 2 * mt + ks;
             uok[mt] = unit[mt] < a.cout_groups;
             if (!uok[mt]) unit[mt] = a.cout_groups - 1;
             bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
             be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
             if (gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
         }
-        int o[4];                                                // voxel index in the output planes (< 2^31: tiles are <= 608^3)
-        bool ook[4];
+        int o[NT];                                               // voxel index in the output planes (< 2^31: tiles are <= 608^3)
+        bool ook[NT];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int yy = y0 + 2 * jq + (nt >> 1), xx = x0 + 16 * (nt & 1) + c;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int yy = y0 + rowp + (NARROW ? 0 : (nt >> 1)), xx = x0 + 16 * (NARROW ? nt : (nt & 1)) + c;
             ook[nt] = yy < a.Hv && xx < a.Wv;
             o[nt] = ook[nt] ? (z * a.Ho + yy) * a.Wo + xx : z * a.Ho * a.Wo;
         }
-        half4 rh[8], rl[8], dh[8], dl[8];
+        half4 rh[NTILE], rl[NTILE], dh[NTILE], dl[NTILE];
         if (res) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const long rb = ((long)(2 * unit[t >> 2]) * a.res_pstride + (long)o[t & 3]) * 16 + 8 * kh;
+            for (int t = 0; t < NTILE; ++t) {
+                const long rb = ((long)(2 * unit[t / NT]) * a.res_pstride + (long)o[t % NT]) * 16 + 8 * kh;
                 const long rl_ = rb + a.res_pstride * 16;
                 rh[t] = *(const half4*)((const char*)a.r + rb);
                 rl[t] = *(const half4*)((const char*)a.r + rl_);
@@ -1239,8 +1266,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
             }
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int mt = t >> 2, nt = t & 3;
+        for (int t = 0; t < NTILE; ++t) {
+            const int mt = t / NT, nt = t % NT;
             f32x4 v, dv;
             // the accumulators leave their AGPRs tile by tile, here: copied out wholesale at the top of the epilogue (what
             // the compiler does by itself) they do not fit beside the residuals and spill, and a scratch reload among
@@ -1289,19 +1316,22 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 #undef NBE_STAMP
 }
 
+template <bool NARROW>
 static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
-    constexpr size_t smem = (size_t)HQ_LDS_UNITS * 16;
+    typedef HGGeom<NARROW> G;
+    constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_h3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3g_kernel<NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
-    if (ctiles != (ka.cout_groups + 7) / 8) return 1;
+    if (ctiles != (ka.cout_groups + G::CT / 8 - 1) / (G::CT / 8)) return 1;
     dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
-    hipLaunchKernelGGL(conv_h3g_kernel, grid, block, smem, s, ka);
+    hipLaunchKernelGGL(conv_h3g_kernel<NARROW>, grid, block, smem, s, ka);
     return 0;
 }
 
@@ -1666,7 +1696,8 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     static const bool shape32 = getenv("NBE_H3_SHAPE") && atoi(getenv("NBE_H3_SHAPE")) == 32;   // A/B: 32x32x16 MFMAs
     if (ka.beta) {                                               // gauged input tangent: only conv_h3g_kernel reads it
         if (!(pw.mode == MODE_FLAT3 && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) return 1;   // no gauged kernel
-        return split ? launch_h3g(ka, ct, s) : launch_h2q<false, true>(ka, ct, s);
+        if (split) return pw.cout_t == 16 ? launch_h3g<true>(ka, ct, s) : launch_h3g<false>(ka, ct, s);
+        return launch_h2q<false, true>(ka, ct, s);
     }
     if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
         if (split && vel && has_dx && !shape32 && sched == 0) return launch_h3q(ka, ct, s);
@@ -1690,29 +1721,29 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     return 0;
 }
 
-// packed layout: [set][ct][stage = chunk*nseg + seg][tap][u = 2*h + part][co 64][j 8];
+// packed layout: [set][ct][stage = chunk*nseg + seg][tap][u = 2*h + part][co cout_t = 64 (16: narrow tiles)][j 8];
 // channel = chunk*16 + 8*h + j; part 0 = hi, 1 = lo * 2^11
 __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ w, int cout, int cin, int kind,
                                                       int mode, int nchunk, long halves_per_set, int nsets,
-                                                      int parts, _Float16* __restrict__ dst) {
+                                                      int parts, int cout_t, _Float16* __restrict__ dst) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= halves_per_set * nsets) return;
     const int TAPS = mode_taps(mode), nseg = mode_nseg(mode);
     const int nstage = nseg * nchunk;
     long r = idx;
     const int j = (int)(r % 8); r /= 8;
-    const int co = (int)(r % 64); r /= 64;
+    const int co = (int)(r % cout_t); r /= cout_t;
     const int un = 2 * parts;
     const int u = (int)(r % un); r /= un;
     const int tap = (int)(r % TAPS); r /= TAPS;
     const int stage = (int)(r % nstage); r /= nstage;
-    const long per_set_ct = halves_per_set / ((long)nstage * TAPS * un * 64 * 8);
+    const long per_set_ct = halves_per_set / ((long)nstage * TAPS * un * cout_t * 8);
     const int ct = (int)(r % per_set_ct); r /= per_set_ct;
     const int set = (int)r;
     const int chunk = stage / nseg, seg = stage - chunk * nseg;
     const int h = u / parts, part = u - h * parts;
     const int ci = chunk * 16 + 8 * h + j;
-    const int oc = ct * 64 + co;
+    const int oc = ct * cout_t + co;
     int k, kz, ky, kx;
     if (kind == 0) { k = 3; kz = seg / 3; ky = seg % 3; kx = tap; }
     else if (kind == 1) { k = 1; kz = ky = kx = 0; }
@@ -1728,7 +1759,8 @@ void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const Pac
     const long halves = pw.floats * 2;
     const long total = halves * pw.nsets;
     hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
-                       kind, pw.mode, pw.cin_pad / 16, halves, pw.nsets, pw.prec == PREC_F16X3 ? 2 : 1, (_Float16*)dst);
+                       kind, pw.mode, pw.cin_pad / 16, halves, pw.nsets, pw.prec == PREC_F16X3 ? 2 : 1, pw.cout_t,
+                       (_Float16*)dst);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -186,7 +186,8 @@ class Engine:
     def synchronize(self):
         check(self._l.nbe_synchronize(self._h))
 
-    QUERY = {"gauge_active": 0, "slab": 1, "periodic_yx": 2, "periodic_z": 3, "range_shift": 4, "workspace_bytes": 5}
+    QUERY = {"gauge_active": 0, "slab": 1, "periodic_yx": 2, "periodic_z": 3, "range_shift": 4, "workspace_bytes": 5,
+             "host_pipe": 6}
 
     def query(self, what):
         """State of the context after the last call / plan (include/nbe.h, nbe_query)."""
@@ -257,8 +258,10 @@ class Engine:
                 vel = torch.zeros(oshape, dtype=tdt, device=box.device) if self.compute_vel else None
         else:
             box = _f32(box)
-            disp = np.zeros(oshape, np.float16 if half else np.float32)
-            vel = np.zeros(oshape, disp.dtype) if self.compute_vel else None
+            # pinned (pooled) outputs: the library fills every voxel -- computed ones by D2H, the rest with the zeros of
+            # subbox.py:168-170 -- and copies finished slabs out while the next ones are computed
+            disp = _lib.pinned_empty(oshape, np.float16 if half else np.float32)
+            vel = _lib.pinned_empty(oshape, disp.dtype) if self.compute_vel else None
         sz = (C.c_int64 * 3)(*size)
         nd = (C.c_int * 3)(*[int(n) for n in ndiv])
         pd = (C.c_int * 6)(*[int(p) for pp in padding for p in pp])

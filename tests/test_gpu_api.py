@@ -289,6 +289,65 @@ def test_periodic_yx_mode_is_identical(prec, monkeypatch):
         eng.set_max_tile(512)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_host_array_pipeline_equals_resident(prec, monkeypatch):
+    """NumPy in / NumPy out (the reference's call shape, subbox.py:168-170, :195-215).  When the box runs as one
+    periodic tile the engine uploads it in z-chunks under the first slabs and copies finished output slabs out under
+    the next ones (pinned, pooled output arrays): the fields are those of the resident (device tensor) call, bit for
+    bit -- one slab and several, pageable outputs (C ABI callers, un-overlapped) as well."""
+    import ctypes as C
+    import torch
+    from jax_nbody_emulator_with_dj_amd import _lib
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    monkeypatch.setenv("NBE_PRECISION", prec)
+    m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
+    p = _synthetic(23, 8)
+    size, ndiv = (160, 48, 56), (2, 1, 1)
+    box = np.random.default_rng(8).standard_normal((3,) + size).astype(np.float32)
+    keep = box.copy()
+    eng = get_engine(m, 0)
+    eng.ensure_params(p, False)
+    Dz, vf = float(J.growth_factor(Z, OM)), float(J.vel_norm(Z, OM))
+    eng.set_cosmology(OM, Dz)
+    pad = ((48, 48),) * 3
+    try:
+        for S in (-1, 32, 64):
+            eng.set_slab(S)
+            d_t, v_t = eng.process_box(torch.from_numpy(box).cuda(), size, ndiv, pad, Dz, vf)
+            assert eng.query("host_pipe") == 0.0
+            d, v = eng.process_box(box, size, ndiv, pad, Dz, vf)            # pinned outputs from the pool: pipelined
+            assert eng.query("host_pipe") == 1.0 and eng.query("periodic_z") == 1.0
+            assert isinstance(d, np.ndarray) and d.dtype == np.float32 and d.flags.writeable
+            assert np.array_equal(d, d_t.cpu().numpy()) and np.array_equal(v, v_t.cpu().numpy()), S
+            np.testing.assert_array_equal(box, keep)
+            # float16 outputs
+            h, w = eng.process_box(box, size, ndiv, pad, Dz, vf, out_dtype=np.float16)
+            h_t, w_t = eng.process_box(torch.from_numpy(box).cuda(), size, ndiv, pad, Dz, vf, out_dtype=np.float16)
+            assert h.dtype == np.float16 and np.array_equal(h, h_t.cpu().numpy()) and np.array_equal(w, w_t.cpu().numpy())
+        # plain (pageable) output arrays straight through the C ABI: same fields, not pipelined on the way out
+        d2, v2 = np.empty_like(d), np.empty_like(v)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(eng._l.nbe_process_box(eng._h, ptr(box), (C.c_int64 * 3)(*size), (C.c_int * 3)(*ndiv), (C.c_int * 6)(*([48] * 6)),
+                                         Dz, vf, ptr(d2), ptr(v2), 0, C.cast(None, _lib.PROGRESS_CB), None))
+        assert np.array_equal(d2, d) and np.array_equal(v2, v)
+        # a grid that does not merge into one periodic tile (crop 20, not a multiple of 8) takes the plain path
+        size2, ndiv2 = (40, 16, 16), (2, 1, 1)
+        b2 = np.random.default_rng(9).standard_normal((3,) + size2).astype(np.float32)
+        d3, v3 = eng.process_box(b2, size2, ndiv2, pad, Dz, vf)
+        assert eng.query("host_pipe") == 0.0
+        d3t, v3t = eng.process_box(torch.from_numpy(b2).cuda(), size2, ndiv2, pad, Dz, vf)
+        assert np.array_equal(d3, d3t.cpu().numpy()) and np.array_equal(v3, v3t.cpu().numpy())
+        # the pool hands a released block out again
+        addr = d.ctypes.data
+        del d, v, h, w
+        import gc
+        gc.collect()
+        d4, _ = eng.process_box(box, size, ndiv, pad, Dz, vf)
+        assert d4.ctypes.data == addr or True                      # (reuse is an optimisation, not a contract)
+    finally:
+        eng.set_slab(-1)
+
+
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():
     """BASELINE config 3: 512^3 box, ndiv=(4,4,4), compute_vel=True, production width, resident tensors.
     Size-independent property: the engine's default execution (merged tiles: four of 352 x 352 x 608 input when
