@@ -87,6 +87,10 @@ struct Layer {
     const float* gout = nullptr;                  // gauge of the output tensor = alpha of its 3x3x3 consumer (+ channel offset)
     const float* a_in = nullptr;                  // general kernels: gauge of the input tensor, folded into dw
     bool g6 = false;                              // 3x3x3 layer whose input arrives in its own gauge: two products, no dw
+    // Skip fusion (conv_h3g_kernel): a block's conv_1 computes the block's 1x1x1 skip as extra groups on the block input.
+    const Layer* fskip = nullptr;                 // conv_1: the block's skip layer, when the block can run fused
+    const float* b_sub = nullptr;                 // skip: beta of the block's conv_1, folded into dW_s~ when fused
+    float* bias_f = nullptr;                      // conv_1: (b_1 + b_s) * act_scale (device, padded like pw.bias)
 };
 
 struct ProfEntry { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
@@ -116,12 +120,14 @@ struct nbe_ctx {
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     bool gauge = false;                           // the loaded network is wired for gauged tangents (style weights, velocity)
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
+    bool fuse = false;                            // ... and the blocks' skips run fused into their conv_1 (f16x3 only)
     int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
     // Range shift of the f16-based arithmetic (include/nbe.h, "Range"): activations and biases of a call are multiplied
     // by act_scale = 2^k (exact), the head divides it out.  flags[0]: bit pattern of max |input| (launch_absmax),
     // flags[1]: a non-finite value was written by the head.
     float act_scale = 1.f;                        // 2^k of the current call
     float bias_scale = 1.f;                       // 2^k the device biases currently carry
+    bool bias_dirty = true;                       // the scaled biases (pw.bias, bias_f) have to be rewritten (new weights)
     float bias_max = 0.f;                         // max |bias| over all layers (host, at load time)
     float preset_absmax = -1.f;                   // >= 0: max |input| supplied by the caller (nbe_set_input_range)
     bool input_finite = true;                     // the input of the current call had no NaN / infinity
@@ -370,6 +376,10 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
     cl.flags |= dbgf;
     const bool g6 = c->gauge_active && L.g6 && has_dx;
     if (c->gauge_active) { cl.gout = L.gout; cl.beta = g6 ? L.beta : nullptr; }
+    if (cl.skw) {                                                // the block's skip runs inside this launch
+        if (!(g6 && c->fuse && L.fskip)) return fail("internal error: fused skip requested for %s/%s", L.block.c_str(), L.layer.c_str());
+        cl.bias = L.bias_f;
+    }
     static const bool no_narrow = getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0;      // A/B switch
     const PackedW& pw = (g6 && L.pwn.w && !no_narrow) ? L.pwn : L.pw;
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
@@ -390,6 +400,7 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
         const int taps = L.kind == 0 ? 27 : L.kind == 2 ? 8 : 1;
         const double gemms = c->vel ? ((has_dx && !g6) ? 3.0 : 2.0) : 1.0;
         c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.cin * taps * gemms;
+        if (cl.skw) c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.fskip->cin * 3.0;   // W_s.x, W_s.dx, dW_s.x
         c->prof_entries[pe].launches += 1;
         if (c->pending.size() > 4096) prof_collect(c);
     }
@@ -409,6 +420,16 @@ static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer)
 // Periodic-yx mode (x.pad = 1): y and x do not shrink -- every 3x3x3 convolution reads its input's wrap-around halo
 // and writes the interior of a tensor of the same padded size, whose halo is filled afterwards; z shrinks as always.
 // (dst: write the block's result there -- a view with the result's geometry -- instead of allocating it)
+static bool block_fused(nbe_ctx* c, const Layer* L1, bool has_dx) { return c->fuse && has_dx && L1->fskip != nullptr; }
+
+// hidden tensor of a block whose input x has `pad`: interior (Hi - sy) x (Wi - sy).  A fused block gives it the row
+// and plane pitch of x (conv_h3g_kernel fetches the skip's patches of x with the offsets of its own input's).
+static Tensor alloc_hidden(nbe_ctx* c, int cmid, int nz, const Tensor& x, bool fused) {
+    const int pad = x.pad, sy = pad ? 0 : 2;
+    if (fused && !pad) return talloc(c, cmid, nz, x.p.H, x.p.W);
+    return tallocp(c, cmid, nz, x.p.H - 2 * pad - sy, x.p.W - 2 * pad - sy, pad);
+}
+
 static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, bool final_act,
                     int cout, int cmid, Tensor* out, const Tensor* dst = nullptr) {
     const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
@@ -416,15 +437,18 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     const int D = x.p.D, H = x.p.H, W = x.p.W, pad = x.pad;
     const int Hi = H - 2 * pad, Wi = W - 2 * pad;                 // interior of x (pad = 0: all of it)
     const int sy = pad ? 0 : 2;                                  // what one 3x3x3 convolution takes off y and x
-    // The second convolution adds the skip as a residual and writes its result over it (every lane reads its residual
-    // elements before it stores the same elements): one full-resolution tensor pair less at the workspace peak.
+    const bool fused = block_fused(c, L1, has_dx);
+    // Unfused: the second convolution adds the skip as a residual and writes its result over it (every lane reads its
+    // residual elements before it stores the same elements): one full-resolution tensor pair less at the workspace peak.
+    // Fused (gauged f16x3): conv_1 computes the skip itself from x -- no skip launch, no residual round trip.
     Tensor s = dst ? *dst : tallocp(c, cout, D - 4, Hi - 2 * sy, Wi - 2 * sy, pad);
-    Tensor h = tallocp(c, cmid, D - 2, Hi - sy, Wi - sy, pad);
+    Tensor h = alloc_hidden(c, cmid, D - 2, x, fused);
     if ((!dst && s.off < 0) || h.off < 0) return fail("workspace exhausted in block %s", name);
     if (dst && (s.p.D != D - 4 || s.p.H != Hi - 2 * sy + 2 * pad || s.p.W != Wi - 2 * sy + 2 * pad || s.pad != pad))
         return fail("internal: destination geometry mismatch in block %s", name);
-    {
-        ConvLaunch cl; cl.in = x.p; cl.in_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
+    const int64_t sk_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);   // skip: centre crop of x by the two convolutions
+    if (!fused) {
+        ConvLaunch cl; cl.in = x.p; cl.in_off = sk_off;
         cl.Dv = D - 4; cl.Hv = Hi - 2 * sy; cl.Wv = Wi - 2 * sy; cl.out = inner(s); cl.flags = 0;
         if (run_conv(c, *Ls, cl, has_dx)) return 1;
     }
@@ -434,8 +458,9 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     }
     fill_halo(c, h);
     {
-        ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = h.p.H - 2; cl.Wv = h.p.W - 2; cl.out = inner(s);
-        cl.res = inner(s); cl.flags = F_RES | (final_act ? F_ACT : 0);
+        ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(s);
+        if (fused) { cl.sk = x.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = final_act ? F_ACT : 0; }
+        else { cl.res = inner(s); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
     }
     fill_halo(c, s);
@@ -453,9 +478,13 @@ static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Te
     const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
     if (!Ls || !L0 || !L1) return fail("missing layers of block %s", name);
     const int H = x.p.H, W = x.p.W, pad = x.pad;
+    const bool fused = block_fused(c, L1, has_dx);
+    if (fused && (h.p.H != H || h.p.W != W)) return fail("internal: hidden tensor of fused block %s lacks the input's pitch", name);
     const Tensor sv = zview(s, js, ns), hv = zview(h, jh, nh);
-    {
-        ConvLaunch cl; cl.in = zview(x, js, ns + 4).p; cl.in_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
+    const Tensor xs = zview(x, js, ns + 4);                      // what the skip of result planes [js, js + ns) reads
+    const int64_t sk_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
+    if (!fused) {
+        ConvLaunch cl; cl.in = xs.p; cl.in_off = sk_off;
         cl.Dv = ns; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(sv); cl.flags = 0;
         if (run_conv(c, *Ls, cl, has_dx)) return 1;
     }
@@ -465,8 +494,9 @@ static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Te
     }
     fill_halo(c, hv);
     {
-        ConvLaunch cl; cl.in = zview(h, js, ns + 2).p; cl.Dv = ns; cl.Hv = h.p.H - 2; cl.Wv = h.p.W - 2; cl.out = inner(sv);
-        cl.res = inner(sv); cl.flags = F_RES | (final_act ? F_ACT : 0);
+        ConvLaunch cl; cl.in = zview(h, js, ns + 2).p; cl.Dv = ns; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(sv);
+        if (fused) { cl.sk = xs.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = final_act ? F_ACT : 0; }
+        else { cl.res = inner(sv); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
     }
     fill_halo(c, sv);
@@ -626,12 +656,14 @@ static int prepare_range(nbe_ctx* c, const float* dev_src, int64_t n, float Dz, 
         }
     }
     c->act_scale = s;
-    if (s != c->bias_scale) {
+    if (s != c->bias_scale || c->bias_dirty) {
         for (auto& kv : c->layers) {
             Layer& L = kv.second;
-            launch_scale(L.bias0, L.pw.bias, L.pw.ctiles * 32 * L.pw.ni, s, c->stream);
+            const int nb = L.pw.ctiles * 32 * L.pw.ni;
+            launch_scale(L.bias0, L.pw.bias, nb, s, c->stream);
+            if (L.fskip) launch_scale(L.bias0, L.bias_f, nb, s, c->stream, L.fskip->bias0);   // fused block: b_1 + b_s
         }
-        c->bias_scale = s;
+        c->bias_scale = s; c->bias_dirty = false;
     }
     c->range_pending = true;
     return 0;
@@ -766,7 +798,9 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     // recomputed, so every layer computes every plane exactly once.
     const int sy = pad ? 0 : 2;
     Tensor h0 = tallocp(c, m, S + 6, Hi - sy, Wi - sy, pad), a = tallocp(c, m, S + 4, Hi - 2 * sy, Wi - 2 * sy, pad);
-    Tensor h1 = tallocp(c, m, S + 2, Hi - 3 * sy, Wi - 3 * sy, pad);
+    const Layer *L01 = find_layer(c, "conv_l01", "conv_1"), *Lr00 = find_layer(c, "conv_r00", "conv_1"), *Lr01 = find_layer(c, "conv_r01", "conv_1");
+    if (!L01 || !Lr00 || !Lr01) return fail("missing conv_1 layers of the level-0 blocks");
+    Tensor h1 = alloc_hidden(c, m, S + 2, a, block_fused(c, L01, true));
     Tensor y0r = pz ? Tensor() : tallocp(c, m, S, Hi - 4 * sy, Wi - 4 * sy, pad);
     if (h0.off < 0 || a.off < 0 || h1.off < 0 || (!pz && y0r.off < 0)) return fail("workspace exhausted (level-0 encoder slabs)");
     for (int z = zlo; z < zhi; z += S) {
@@ -869,8 +903,8 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     // Persistent slab tensors of the level-0 decoder, with the same carry-over of the overlaps (8 / 6 / 4 / 2 planes of
     // the concat tensor, the hidden and the result of conv_r00, the hidden of conv_r01).
     const int Hs = skip0.p.H - 2 * pad, Ws = skip0.p.W - 2 * pad;
-    Tensor cat = tallocp(c, 2 * m, S + 8, Hs, Ws, pad), hq = tallocp(c, 2 * m, S + 6, Hs - sy, Ws - sy, pad);
-    Tensor q = tallocp(c, m, S + 4, Hs - 2 * sy, Ws - 2 * sy, pad), hy = tallocp(c, m, S + 2, Hs - 3 * sy, Ws - 3 * sy, pad);
+    Tensor cat = tallocp(c, 2 * m, S + 8, Hs, Ws, pad), hq = alloc_hidden(c, 2 * m, S + 6, cat, block_fused(c, Lr00, true));
+    Tensor q = tallocp(c, m, S + 4, Hs - 2 * sy, Ws - 2 * sy, pad), hy = alloc_hidden(c, m, S + 2, q, block_fused(c, Lr01, true));
     Tensor y = tallocp(c, c->out_chan, S, Hs - 4 * sy, Ws - 4 * sy, pad);
     if (cat.off < 0 || hq.off < 0 || q.off < 0 || hy.off < 0 || y.off < 0) return fail("workspace exhausted (level-0 decoder slabs)");
     for (int z = 0; z < Yo; z += S) {
@@ -972,12 +1006,12 @@ static void free_layers(nbe_ctx* c) {
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
-        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pwn.w);
+        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pwn.w); (void)hipFree(L.bias_f);
         (void)hipFree(L.alpha); (void)hipFree(L.beta);
     }
     c->layers.clear();
-    c->bias_scale = 1.f; c->bias_max = 0.f;
-    c->have_weights = false; c->modulated = false; c->gauge = false; c->gauge_active = false;
+    c->bias_scale = 1.f; c->bias_max = 0.f; c->bias_dirty = true;
+    c->have_weights = false; c->modulated = false; c->gauge = false; c->gauge_active = false; c->fuse = false;
 }
 
 static int kind_of(const nbe_layer_desc& d, int* kind) {
@@ -1044,7 +1078,19 @@ static int wire_gauge(nbe_ctx* c) {
         L0->gout = L1->alpha;                                    // the hidden tensor is read by conv_1 only
         L1->g6 = true;
         if (strcmp(b, "conv_l00")) { L0->g6 = true; Ls->a_in = L0->alpha; }   // conv_l00 reads the input field: no tangent
+        // the skip can run inside conv_1 (conv_h3g_kernel<false>): f16x3, the block input has a tangent, the wide tile,
+        // and the groups of both fit the kernel's table
+        static const bool no_fuse = getenv("NBE_FUSE") && atoi(getenv("NBE_FUSE")) == 0;        // A/B switch
+        if (c->prec == PREC_F16X3 && !no_fuse && strcmp(b, "conv_l00") && !L1->pwn.w &&
+            3 * (L1->pw.cin_pad / 16) + Ls->pw.cin_pad / 16 <= NBE_MAX_GROUPS) {
+            L1->fskip = Ls; Ls->b_sub = L1->beta;
+            const int nb = L1->pw.ctiles * 32 * L1->pw.ni;
+            HIPCHK(hipMalloc((void**)&L1->bias_f, nb * 4));
+        }
     }
+    // every gauged 3x3x3 layer must fit the group table of conv_h3g_kernel
+    for (auto& kv : c->layers)
+        if (kv.second.g6 && 3 * (kv.second.pw.cin_pad / 16) > NBE_MAX_GROUPS) { c->gauge = false; return 0; }
     lay("down_l0", "conv_0")->a_in = lay("conv_r00", "conv_0")->alpha;    // they read conv_l01 / conv_l1 / conv_l2's output
     lay("down_l1", "conv_0")->a_in = lay("conv_r1", "conv_0")->alpha;
     lay("down_l2", "conv_0")->a_in = lay("conv_r2", "conv_0")->alpha;
@@ -1112,6 +1158,7 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
         }
     }
     if (wire_gauge(c)) return 1;
+    if (!c->gauge) return 0;                                    // a layer too wide for the gauged kernel's group table
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         auto ia = al.find(kv.first);
@@ -1127,13 +1174,16 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
         const nbe_layer_desc& d = *by_name[key];
         Layer& L = c->layers[key];
         const std::vector<double>& a = al[std::string(reader) + "/conv_0"];
+        // a skip that runs inside its block's conv_1 (Layer::b_sub): the kernel's epilogue adds beta_1[o] * (W_s.x) as well
+        const std::vector<double>* bsub = L.b_sub ? &be[std::string(b) + "/conv_1"] : nullptr;
         const int k3 = d.k * d.k * d.k;
         std::vector<float> eff((size_t)d.cout * d.cin * k3);
         for (int o = 0; o < d.cout; ++o)
             for (int i = 0; i < d.cin; ++i)
                 for (int k = 0; k < k3; ++k) {
                     const size_t e = ((size_t)o * d.cin + i) * k3 + k;
-                    eff[e] = (float)((double)d.dweight[e] - (double)d.weight[e] * a[off + i]);
+                    eff[e] = (float)((double)d.dweight[e] - (double)d.weight[e] * a[off + i]
+                                     - (bsub ? (double)d.weight[e] * (*bsub)[o] : 0.0));
                 }
         HIPCHK(hipMemcpy(L.dwn, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
         launch_pack(L.dwn, d.cout, d.cin, L.kind, L.pw, L.pw.dw, c->stream);
@@ -1146,7 +1196,8 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
     if (fold("down_l0", "conv_0", "conv_r00", 0) || fold("down_l1", "conv_0", "conv_r1", 0) ||
         fold("down_l2", "conv_0", "conv_r2", 0)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->gauge_active = true;
+    c->gauge_active = c->gauge;
+    c->fuse = c->gauge && c->prec == PREC_F16X3;
     return 0;
 }
 
@@ -1181,7 +1232,9 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
         HIPCHK(hipMalloc((void**)&pw.bias, nb * 4));
         HIPCHK(hipMemset(pw.bias, 0, nb * 4));
         HIPCHK(hipMemcpy(pw.bias, d.bias, d.cout * 4, hipMemcpyHostToDevice));
-        if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && d.cout <= 16 && !L.first) {
+        // (cout <= 4: the head convolution 64 -> 3.  Narrow test models, cout 8 or 16, stay on the wide tile so that they
+        // exercise what production-width layers run, skip fusion included.)
+        if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && d.cout <= 4 && !L.first) {
             PackedW& pn = L.pwn;                               // same layer, 16-cout tiles (conv_h3g_kernel<true>)
             pn = pw; pn.w = nullptr; pn.dw = nullptr;
             pn.cout_t = 16; pn.ctiles = 1;
@@ -1340,13 +1393,16 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
     }
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
+        // (map order: a block's conv_1, which writes its beta, comes before its skip, which folds it in as b_sub)
         launch_modulate(L.weight, L.sw, L.sb, L.cout, L.cin, L.k * L.k * L.k, s0, s1, c->eps, L.first ? 1 : 0,
-                        L.wn, c->vel ? L.dwn : nullptr, c->stream, use_gauge ? L.a_in : nullptr, use_gauge ? L.beta : nullptr);
+                        L.wn, c->vel ? L.dwn : nullptr, c->stream, use_gauge ? L.a_in : nullptr, use_gauge ? L.beta : nullptr,
+                        use_gauge ? L.b_sub : nullptr);
         launch_pack(L.wn, L.cout, L.cin, L.kind, L.pw, L.pw.w, c->stream);
         if (L.pwn.w) launch_pack(L.wn, L.cout, L.cin, L.kind, L.pwn, L.pwn.w, c->stream);
         if (c->vel && !(use_gauge && L.g6)) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pw, L.pw.dw, c->stream);
     }
     c->gauge_active = use_gauge;
+    c->fuse = use_gauge && c->prec == PREC_F16X3;               // blocks with Layer::fskip run their skip inside conv_1
     HIPCHK(hipGetLastError());
     c->modulated = true; c->mod_Om = Om; c->mod_Dz = Dz;
     return 0;

@@ -34,6 +34,10 @@ inline constexpr bool prec_is_half(int prec) { return prec == PREC_F16X3 || prec
 inline constexpr int prec_parts(int prec) { return prec == PREC_F16X3 ? 2 : 1; }
 constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
 
+// conv_h3g_kernel reads its per-group sources from a table in its arguments: 3 * Cin / 16 groups of the layer
+// + Cin_skip / 16 of a fused skip must fit
+constexpr int NBE_MAX_GROUPS = 64;
+
 enum ConvMode { MODE_FLAT3 = 0, MODE_FLAT1 = 1, MODE_DOWN = 2 };
 enum ConvFlags { F_ACT = 1, F_RES = 2 };
 
@@ -71,6 +75,14 @@ struct ConvLaunch {
     int set = 0;             // weight set (parity) index
     const float* gout = nullptr;   // tangent gauge of the output (per cout), f16x3 kernels only
     const float* beta = nullptr;   // gauged input: two-product tangent with this per-cout factor (3x3x3 f16x3 only)
+    const float* bias = nullptr;   // replaces the layer's own bias (a block's conv_1 with its skip fused: b_1 + b_s)
+    // gauged f16x3 3x3x3 kernel (wide tile) only:
+    Planes in2;                    // channels >= csplit_ch of the input come from here (same geometry and offsets as `in`)
+    int csplit_ch = 0;             // 0: single input tensor
+    Planes sk, sk2;                // fused 1x1x1 skip: its input (the block input), sk2 = its channels >= sk_split_ch
+    int sk_split_ch = 0;
+    int64_t sk_off = 0;            // flat offset in sk of the voxel aligned with output (0, 0, 0)
+    const PackedW* skw = nullptr;  // the skip layer's packed weights (FLAT1): w = W_s, dw = dW_s~
 };
 
 // 0 on success; 1 = the layer / flag combination has no kernel (an engine bug, reported through nbe_last_error)
@@ -81,7 +93,7 @@ int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, h
 void launch_modulate(const float* weight, const float* style_weight, const float* style_bias,
                      int cout, int cin, int k3, float s0, float s1, float eps, int first_layer,
                      float* w_n, float* dw_tot /*nullable*/, hipStream_t s,
-                     const float* a_in = nullptr, float* beta_out = nullptr);
+                     const float* a_in = nullptr, float* beta_out = nullptr, const float* b_sub = nullptr);
 // alpha[ci] = (ds/dDz) / s of the style modulation of a layer; *flag |= 1 where s is (numerically) zero or |alpha| > 64
 void launch_style_alpha(const float* style_weight, const float* style_bias, int cin, float s0, float s1,
                         float* alpha, int* flag, hipStream_t s);
@@ -109,8 +121,8 @@ void launch_head(const Planes& y, const Planes& xin, int c0, int C, const HeadSc
 // *out_bits = max(*out_bits, bit pattern of |src[i]|) over n floats (non-negative floats order like their bit
 // patterns; a NaN or an infinity gives >= 0x7f800000)
 void launch_absmax(const float* src, int64_t n, unsigned* out_bits, hipStream_t s);
-// dst[i] = src[i] * f
-void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s);
+// dst[i] = (src[i] + (src2 ? src2[i] : 0)) * f
+void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s, const float* src2 = nullptr);
 
 // periodic y/x halo of width `pad` of a tensor whose interior has been written; dst = src extended periodically in y/x
 void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s);

@@ -247,13 +247,27 @@ int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, h
     ka.y = L.out.x; ka.dy = L.out.dx; ka.out_pstride = L.out.pstride; ka.out_g0 = L.out_g0;
     ka.Ho = L.out.H; ka.Wo = L.out.W; ka.osz = L.osz; ka.oz = L.oz; ka.oy = L.oy; ka.ox = L.ox;
     ka.r = L.res.x; ka.dr = L.res.dx; ka.res_pstride = L.res.pstride;
-    ka.bias = pw.bias;
+    ka.bias = L.bias ? L.bias : pw.bias;
     ka.w = pw.w + (size_t)L.set * pw.floats;
     ka.dw = pw.dw ? pw.dw + (size_t)L.set * pw.floats : nullptr;
     ka.nchunk = pw.cin_pad / prec_ck(pw.prec, pw.mode);
     ka.cout_groups = prec_is_half(pw.prec) ? (pw.cout + 7) / 8 : (pw.cout + 3) / 4;
     ka.flags = L.flags;
     ka.gout = L.gout; ka.beta = L.beta;
+    // second input segment and fused skip (conv_h3g_kernel<false>; every other kernel ignores them, and the launcher
+    // refuses them where they would be ignored)
+    ka.x2 = L.in2.x; ka.dx2 = L.in2.dx; ka.in2_pstride = L.in2.pstride;
+    ka.csplit = L.csplit_ch > 0 ? L.csplit_ch / 16 : (1 << 30);
+    ka.xs = ka.dxs = ka.xs2 = ka.dxs2 = nullptr; ka.s_pstride = ka.s2_pstride = 0; ka.s_csplit = 1 << 30;
+    ka.ws = ka.dws = nullptr; ka.nskip = 0; ka.dws_delta = 0;
+    if (L.skw) {
+        if (L.sk.H != L.in.H || L.sk.W != L.in.W) return 1;                   // the fused skip shares the input's pitch
+        // patch origin of output tile (z, y0, x0) = the skip's voxel minus one row and one column (centre tap)
+        const int64_t o = (L.sk_off - L.sk.W - 1) * 4;                        // floats: one voxel of a plane is 16 bytes
+        ka.xs = L.sk.x + o; ka.dxs = L.sk.dx + o; ka.s_pstride = L.sk.pstride;
+        if (L.sk_split_ch > 0) { ka.xs2 = L.sk2.x + o; ka.dxs2 = L.sk2.dx + o; ka.s2_pstride = L.sk2.pstride; ka.s_csplit = L.sk_split_ch / 16; }
+        ka.ws = L.skw->w; ka.dws = L.skw->dw; ka.nskip = L.skw->cin_pad / 16;
+    }
     ka.ntiles = (int)((ka.Q + TILE_VOX - 1) / TILE_VOX);
     if (prec_is_half(pw.prec)) return launch_conv_h3(pw, ka, vel, has_dx, s);
     const int ct = pw.ctiles;
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
                                                        int cin, int k3, float s0, float s1, float eps,
                                                        int first_layer, float* __restrict__ w_n,
                                                        float* __restrict__ dw_tot, const float* __restrict__ a_in,
-                                                       float* __restrict__ beta_out) {
+                                                       float* __restrict__ beta_out, const float* __restrict__ b_sub) {
     __shared__ double scratch[4];
     const int co = blockIdx.x;
     const int n = cin * k3;
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
             float d = dws / norm + w * dnorm;
             if (first_layer) d += wn * inv_dz;
             if (a_in) d -= wn * a_in[ci];                        // the input's tangent is stored as dx + a_in * x
+            if (b_sub) d -= wn * b_sub[co];                      // a skip fused into a gauged conv_1 (conv_h3g_kernel)
             dw_tot[(size_t)co * n + e] = d;
         }
     }
@@ -342,9 +357,9 @@ __global__ __launch_bounds__(256) void modulate_kernel(const float* __restrict__
 
 void launch_modulate(const float* weight, const float* style_weight, const float* style_bias,
                      int cout, int cin, int k3, float s0, float s1, float eps, int first_layer,
-                     float* w_n, float* dw_tot, hipStream_t s, const float* a_in, float* beta_out) {
+                     float* w_n, float* dw_tot, hipStream_t s, const float* a_in, float* beta_out, const float* b_sub) {
     hipLaunchKernelGGL(modulate_kernel, dim3(cout), dim3(256), 0, s, weight, style_weight, style_bias,
-                       cin, k3, s0, s1, eps, first_layer, w_n, dw_tot, a_in, beta_out);
+                       cin, k3, s0, s1, eps, first_layer, w_n, dw_tot, a_in, beta_out, b_sub);
 }
 
 __global__ void style_alpha_kernel(const float* __restrict__ sw, const float* __restrict__ sb, int cin, float s0,
@@ -626,13 +641,13 @@ void launch_absmax(const float* src, int64_t n, unsigned* out_bits, hipStream_t 
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, (long)n, out_bits);
 }
 
-__global__ void scale_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float f) {
+__global__ void scale_kernel(const float* __restrict__ src, const float* __restrict__ src2, float* __restrict__ dst, int n, float f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i] * f;
+    if (i < n) dst[i] = (src[i] + (src2 ? src2[i] : 0.f)) * f;
 }
 
-void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, f);
+void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s, const float* src2) {
+    if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, src2, dst, n, f);
 }
 
 }  // namespace nbe

@@ -1084,14 +1084,32 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 
     const unsigned lane16 = (unsigned)lane * 16u;
     // ---- DMA of group g into buffers g & 1: 36 wave-instructions of weights (5 slots per wave), 24 + 24 of the
-    // x and dx~ patches (3 + 3 slots per wave)
-    const long wct = (long)ct * ngroups * WGU;
-    auto dma_w = [&](int g, int t) {
-        const int n = wave + 8 * t;
-        if (n >= G::NWI) return;
-        dma16s((const char*)a.w + (wct + (long)g * WGU + n * 64) * 16, lane16, lds + (g & 1) * WGU + n * 64);
+    // x and dx~ patches (3 + 3 slots per wave).
+    // Groups [0, ngroups) are the (chunk, dz) groups of the 3x3x3 layer; chunks >= csplit come from a second tensor of
+    // the same geometry (the decoder's concat([skip, up]) without a materialised concat tensor, core :168-169).
+    // Groups [ngroups, ngroups + nskip) are the block's 1x1x1 skip (style_blocks_vel.py:108-123) fused into this,
+    // the block's last, convolution: one 16-channel chunk of the BLOCK INPUT each (its patch placed so that the centre
+    // tap is the skip's voxel), weights [W_s | dW_s~] of that chunk -- see the skip body below.
+    const int nskip = NARROW ? 0 : a.nskip;
+    // Per group the host has prepared {x, dx, w, plane stride} (ConvKArgs::gs, in the kernel-argument segment): all that
+    // depends on the group but not on the tile.  The tile adds its patch origin and its cout tile.  (Computing the
+    // sources here from the dozen pointers and strides they derive from kept ~80 more SGPRs alive through the loop.)
+    // (the skip's input has the row and plane pitch of the layer's input -- the engine allocates the block's hidden
+    // tensor with the pitch of the block input -- so one patch origin and one set of per-lane offsets serve both)
+    const long to = (((long)z * a.H + y0) * a.W + x0) * 16;
+    const long wcm = (long)ct * ngroups * WGU * 16, wcs = (long)ct * nskip * 256 * 16;
+    struct Nxt { const char *x, *dx, *w0; long psb; bool sk; } nx;   // sources of the group being fetched
+    auto set_next = [&](int g) {
+        const ConvGroupSrc e = a.gs[g];
+        const bool sk = !NARROW && g >= ngroups;
+        nx.x = e.x + to; nx.dx = e.dx + to; nx.psb = e.psb; nx.w0 = e.w + (sk ? wcs : wcm); nx.sk = sk;
     };
-    unsigned xoff[3];
+    auto dma_w = [&](int buf, int t) {
+        const int n = wave + 8 * t;
+        if (!nx.sk) { if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, lane16, lds + buf * WGU + n * 64); }
+        else if (n < 8) dma16s(nx.w0 + (n < 4 ? 0 : a.dws_delta) + (long)(n & 3) * 1024, lane16, lds + buf * WGU + n * 64);
+    };
+    unsigned xoff[3];                                            // per-lane byte offset inside a patch plane
     bool xval[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -1102,20 +1120,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         const int row = uu / HP_RS, col = uu - row * HP_RS;
         xoff[t] = (unsigned)(row * a.W + col) * 16u;
     }
-    auto patch_offset = [&](int g) -> long {                     // g = chunk*3 + dz
-        const int chunk = g / 3, dz = g - chunk * 3;
-        return ((long)chunk * 4 * a.in_pstride + ((long)(z + dz) * a.H + y0) * a.W + x0) * 16;
-    };
-    auto dma_x = [&](int tensor, int t, long xo, int buf) {
+    auto dma_x = [&](int tensor, int t, int buf) {
         const int n = wave + 8 * t, pl = n / 6, k = n - 6 * pl;
         if (xval[t])
-            dma16s((const char*)(tensor ? a.dx : a.x) + xo + (long)pl * a.in_pstride * 16, xoff[t],
+            dma16s((tensor ? nx.dx : nx.x) + (long)pl * nx.psb, xoff[t],
                    lds + XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HQ_PP + k * 64);
     };
-    auto dma_slot = [&](int k, int g, long xo) {                 // slot k of the NWS + 6 (11 / 8) of group g
-        if (k < NWS) dma_w(g, k);
-        else if (k < NWS + 3) dma_x(0, k - NWS, xo, g & 1);
-        else if (k < NWS + 6) dma_x(1, k - NWS - 3, xo, g & 1);
+    auto dma_slot = [&](int k, int buf) {                        // slot k of the NWS + 6 (11 / 8) of the group in `nx`
+        if (k < NWS) dma_w(buf, k);
+        else if (k < NWS + 3) dma_x(0, k - NWS, buf);
+        else if (k < NWS + 6) dma_x(1, k - NWS - 3, buf);
     };
 
     f32x4 ym[NTILE], yc[NTILE], dm[NTILE], dc[NTILE];            // AGPRs, updated in place (see conv_h3q_kernel)
@@ -1142,14 +1156,14 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     };
     // one product on the wave tile: NTILE MFMAs; slot >= 0: DMA slots `slot`, `slot + 1` of group gn, one after each
     // MFMA row (wide) or both after the product (narrow)
-    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int gn, long xo, bool px) {
+    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px) {
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
             mm(acc[t], A[t / NT], B[t % NT]);
             if (slot >= 0 && (t % NT) == NT - 1) {
                 if (px) {
-                    if (MT == 2) dma_slot(slot + t / NT, gn, xo);
-                    else { dma_slot(slot, gn, xo); dma_slot(slot + 1, gn, xo); }
+                    if (MT == 2) dma_slot(slot + t / NT, nb);
+                    else { dma_slot(slot, nb); dma_slot(slot + 1, nb); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1160,27 +1174,26 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     // A tap pair: six products.  On entry wh, xl and xh of the pair are loaded (or in flight); preXl / preW / preXh
     // request those of whatever follows as soon as the registers are free.  Dependent MFMAs are >= 8 MFMAs apart.
     // (mid: after the third product every LDS read of the pair has been issued -- the group's barrier goes there)
-    auto pair = [&](int slot0, int gn, long xo, bool px, int wa, int xp, auto&& preXl, auto&& preW, auto&& preXh,
-                    auto&& mid) {
+    auto pair = [&](int slot0, int nb, bool px, int wa, int xp, auto&& preXl, auto&& preW, auto&& preXh, auto&& mid) {
         LA(wl, wa + CT + aP); LB(dxh, xp + HQ_XT);
-        NBE_SB; MM8(yc, wh, xl, slot0, gn, xo, px); NBE_SB;
+        NBE_SB; MM8(yc, wh, xl, slot0, nb, px); NBE_SB;
         LB(dxl, xp + HQ_XT + HQ_PP);
-        NBE_SB; MM8(ym, wh, xh, slot0 < 0 ? -1 : slot0 + 2, gn, xo, px); NBE_SB;
-        MM8(dm, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, gn, xo, px); NBE_SB;
+        NBE_SB; MM8(ym, wh, xh, slot0 < 0 ? -1 : slot0 + 2, nb, px); NBE_SB;
+        MM8(dm, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px); NBE_SB;
         mid();
         preXl();
-        NBE_SB; MM8(dc, wh, dxl, slot0 < 0 ? -1 : slot0 + 6, gn, xo, px); NBE_SB;
+        NBE_SB; MM8(dc, wh, dxl, slot0 < 0 ? -1 : slot0 + 6, nb, px); NBE_SB;
         preW();
-        NBE_SB; MM8(yc, wl, xh, slot0 < 0 ? -1 : slot0 + 8, gn, xo, px); NBE_SB;
+        NBE_SB; MM8(yc, wl, xh, slot0 < 0 ? -1 : slot0 + 8, nb, px); NBE_SB;
         preXh();
-        NBE_SB; MM8(dc, wl, dxh, slot0 < 0 ? -1 : slot0 + 10, gn, xo, px); NBE_SB;
+        NBE_SB; MM8(dc, wl, dxh, slot0 < 0 ? -1 : slot0 + 10, nb, px); NBE_SB;
     };
 
     // ---- prologue: group 0
     {
-        const long x0off = patch_offset(0);
+        set_next(0);
 #pragma unroll
-        for (int k = 0; k < NWS + 6; ++k) dma_slot(k, 0, x0off);
+        for (int k = 0; k < NWS + 6; ++k) dma_slot(k, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         NBE_STAMP(0)
@@ -1189,43 +1202,77 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
     for (int g = 0; g < ngroups; ++g) {
-        const bool px = g + 1 < ngroups;
-        const long xo = px ? patch_offset(g + 1) : 0;
+        const bool px = g + 1 < ngroups + nskip;
+        if (px) set_next(g + 1);
+        const int nb = (g + 1) & 1;
         const int wb = (g & 1) * WGU, xb = XBASE + (g & 1) * HQ_XB;
-        const int wbn = WGU - wb, xbn = XBASE + ((g + 1) & 1) * HQ_XB;
+        const int wbn = WGU - wb, xbn = XBASE + nb * HQ_XB;
         half8 a1w[MT], a0[MT], b1x[NT], b1d[NT];
         // single tap 4 = (dy 1, dx 1): the lane-group halves select the PART: [wh|wl].[xl|xh] and [0|wh].[xl|xh]
         const int aS1 = wb + 4 * TAPU + (2 * kh + ks) * CT + rowc + c;
         const int aS0 = wb + 4 * TAPU + (2 * kh) * CT + rowc + c;
         const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + rowp * HP_RS + c + SH4;
 
-        pair(0, g + 1, xo, px, wb, xb + bP1,                                           // taps (0,1) + the DMA of group g+1
+        pair(0, nb, px, wb, xb + bP1,                                                  // taps (0,1) + the DMA of group g+1
              [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
              [&] {});
-        pair(-1, g + 1, xo, px, wb + 2 * TAPU, xb + 2 + bP32,                        // taps (2,3)
+        pair(-1, nb, px, wb + 2 * TAPU, xb + 2 + bP32,                                 // taps (2,3)
              [&] { LB(b1x, bS1); }, [&] { LA(a1w, aS1); LA(a0, aS0); }, [&] { LB(b1d, bS1 + HQ_XT); }, [&] {});
         {
             const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a0[mt] = ks ? a0[mt] : zero;       // [0 | wh]
         }
-        NBE_SB; MM8(yc, a1w, b1x, -1, 0, 0, false); NBE_SB;                  // wh.xl + wl.xh
+        NBE_SB; MM8(yc, a1w, b1x, -1, 0, false); NBE_SB;                     // wh.xl + wl.xh
         LB(xl, xb + SH5 + bP32 + HQ_PP);
-        NBE_SB; MM8(ym, a0, b1x, -1, 0, 0, false); NBE_SB;                   // wh.xh
+        NBE_SB; MM8(ym, a0, b1x, -1, 0, false); NBE_SB;                      // wh.xh
         LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
-        NBE_SB; MM8(dc, a1w, b1d, -1, 0, 0, false); NBE_SB;                  // wh.dxl + wl.dxh
-        MM8(dm, a0, b1d, -1, 0, 0, false); NBE_SB;                           // wh.dxh
-        pair(-1, g + 1, xo, px, wb + 5 * TAPU, xb + SH5 + bP32,                      // taps (5,6)
+        NBE_SB; MM8(dc, a1w, b1d, -1, 0, false); NBE_SB;                     // wh.dxl + wl.dxh
+        MM8(dm, a0, b1d, -1, 0, false); NBE_SB;                              // wh.dxh
+        pair(-1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                               // taps (5,6)
              [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
              [&] {});
         // taps (7,8).  The group's one barrier sits after the third product: by then this wave has read everything it
         // needs from the buffers of group g, and all of group g+1 has landed once every wave has waited for its own
         // DMA -- the first operands of group g+1 are requested under the last three products.
-        pair(-1, g + 1, xo, px, wb + 7 * TAPU, xb + SH7 + bP1,
-             [&] { if (px) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (px) LA(wh, wbn + aP); }, [&] { if (px) LB(xh, xbn + bP1); },
+        const bool pm = g + 1 < ngroups;                             // the next group is a 3x3x3 group (not a skip group)
+        pair(-1, nb, px, wb + 7 * TAPU, xb + SH7 + bP1,
+             [&] { if (pm) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (pm) LA(wh, wbn + aP); }, [&] { if (pm) LB(xh, xbn + bP1); },
              [&] { NBE_STAMP(1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); NBE_STAMP(2)
                    asm volatile("s_barrier" ::: "memory"); NBE_STAMP(3) });
         NBE_STAMP(4)
+    }
+    // ---- the block's 1x1x1 skip, one 16-channel chunk of the block input per group.  With the block input x stored
+    // in the gauge a of its 3x3x3 reader (dx~ = dx + a x) the skip's tangent W_s.dx + dW_s.x is
+    //     W_s.dx~ + (dW_s - W_s (.) a) . x,
+    // and this kernel's epilogue adds beta[o] * (everything accumulated in y), so the weight the host packs as dW_s~ is
+    //     dW_s - W_s (.) a[i] - beta[o] W_s
+    // (launch_modulate a_in / b_sub): y += W_s.x,  dy += W_s.dx~ + dW_s~.x -- six products on the centre tap, parts
+    // paired in K as for tap 4 above: [wh|wl].[xl|xh] -> correction, [0|wh].[xl|xh] -> main.
+    if (!NARROW) {
+        for (int sc = 0; sc < nskip; ++sc) {
+            const int g = ngroups + sc;
+            const bool px = sc + 1 < nskip;
+            if (px) set_next(g + 1);
+            const int nb = (g + 1) & 1;
+            const int wb = (g & 1) * WGU, xb = XBASE + (g & 1) * HQ_XB;
+            half8 a1w[MT], a0[MT], a1d[MT], a0d[MT], b1x[NT], b1d[NT];
+            const int aS1 = wb + (2 * kh + ks) * CT + rowc + c, aS0 = wb + (2 * kh) * CT + rowc + c;
+            const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + rowp * HP_RS + c + SH4;
+            LA(a1w, aS1); LB(b1x, bS1); LA(a0, aS0); LB(b1d, bS1 + HQ_XT); LA(a1d, aS1 + 4 * CT); LA(a0d, aS0 + 4 * CT);
+            {
+                const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { a0[mt] = ks ? a0[mt] : zero; a0d[mt] = ks ? a0d[mt] : zero; }
+            }
+            NBE_SB; MM8(yc, a1w, b1x, 0, nb, px); NBE_SB;                    // W_s.x, correction terms
+            MM8(ym, a0, b1x, 2, nb, px); NBE_SB;                             //        main term
+            MM8(dc, a1w, b1d, 4, nb, px); NBE_SB;                            // W_s.dx~
+            MM8(dm, a0, b1d, 6, nb, px); NBE_SB;
+            MM8(dc, a1d, b1x, 8, nb, px); NBE_SB;                            // dW_s~.x
+            MM8(dm, a0d, b1x, 10, nb, px); NBE_SB;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
     }
 #undef NBE_SB
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
@@ -1330,6 +1377,24 @@ static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
     if (ctiles != (ka.cout_groups + G::CT / 8 - 1) / (G::CT / 8)) return 1;
+    const int ngroups = 3 * ka.nchunk, nskip = NARROW ? 0 : ka.nskip;
+    if (ngroups + nskip > NBE_MAX_GROUPS) return 1;              // the engine does not wire such a network for this kernel
+    for (int g = 0; g < ngroups; ++g) {
+        const int chunk = g / 3, dz = g - chunk * 3;
+        const bool second = chunk >= ka.csplit;
+        const long ps = second ? ka.in2_pstride : ka.in_pstride;
+        const long off = ((long)(second ? chunk - ka.csplit : chunk) * 4 * ps + (long)dz * ka.H * ka.W) * 16;
+        ka.gs[g] = {(const char*)(second ? ka.x2 : ka.x) + off, (const char*)(second ? ka.dx2 : ka.dx) + off,
+                    (const char*)ka.w + (long)g * G::WG * 16, ps * 16};
+    }
+    for (int sc = 0; sc < nskip; ++sc) {
+        const bool second = sc >= ka.s_csplit;
+        const long ps = second ? ka.s2_pstride : ka.s_pstride;
+        const long off = (long)(second ? sc - ka.s_csplit : sc) * 4 * ps * 16;
+        ka.gs[ngroups + sc] = {(const char*)(second ? ka.xs2 : ka.xs) + off, (const char*)(second ? ka.dxs2 : ka.dxs) + off,
+                               (const char*)ka.ws + (long)sc * 256 * 16, ps * 16};
+    }
+    ka.dws_delta = nskip ? (const char*)ka.dws - (const char*)ka.ws : 0;
     dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
     hipLaunchKernelGGL(conv_h3g_kernel<NARROW>, grid, block, smem, s, ka);
     return 0;
@@ -1690,6 +1755,8 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
     static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
     const bool split = pw.prec == PREC_F16X3;
+    // a second input segment / a fused skip exist only in the wide gauged f16x3 kernel
+    if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split && pw.cout_t != 16)) return 1;
 #define NBE_VD(F, ...)                                                          \
     if (vel) { if (has_dx) F<__VA_ARGS__, true, true>(ka, ct, s); else F<__VA_ARGS__, true, false>(ka, ct, s); } \
     else F<__VA_ARGS__, false, false>(ka, ct, s);

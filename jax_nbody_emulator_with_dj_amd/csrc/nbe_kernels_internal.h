@@ -12,6 +12,9 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define NBE_LDS_AS __attribute__((address_space(3)))
 #define NBE_GLB_AS __attribute__((address_space(1)))
 
+// conv_h3g_kernel: what group g of a launch reads, prepared by the launcher (everything that does not depend on the tile)
+struct ConvGroupSrc { const char* x; const char* dx; const char* w; long psb; };
+
 // kernel arguments of every convolution variant (POD, passed by value)
 struct ConvKArgs {
     const float* x; const float* dx; long in_pstride;
@@ -26,6 +29,16 @@ struct ConvKArgs {
     // tangent gauge (f16x3 style path, see conv_h3g_kernel): per-cout vectors, either may be NULL
     const float* gout;       // the stored tangent is dy + gout[o] * y
     const float* beta;       // the input tangent is in this layer's gauge: dy = W.dx~ + beta[o] * (W.x), no dW
+    // conv_h3g_kernel<false> only.  Second K-segment of the input: chunks >= csplit are read from x2 / dx2 (same D, H, W
+    // and offsets as x; its own plane stride) -- concat([skip, up]) without a concat tensor.  csplit >= nchunk: unused.
+    const float* x2; const float* dx2; long in2_pstride; int csplit;
+    // The block's 1x1x1 skip fused into its last 3x3x3 convolution: nskip 16-channel chunks of the block input xs / dxs
+    // (chunks >= s_csplit from xs2 / dxs2), row and plane pitch (H, W) of x, pointers already offset so that the centre
+    // tap of the patch of output tile (z, y0, x0) is the skip's voxel; ws / dws = the skip layer's FLAT1-packed W_s / dW_s~.
+    const float* xs; const float* dxs; long s_pstride; const float* xs2; const float* dxs2; long s2_pstride; int s_csplit;
+    const float* ws; const float* dws; int nskip;
+    long dws_delta;          // dws - ws in bytes
+    ConvGroupSrc gs[NBE_MAX_GROUPS];
 };
 
 __device__ __forceinline__ void dma16(const float* src, f32x4* dst_wave_base) {
