@@ -220,8 +220,11 @@ def main():
         emu.processor.params = params
         models.get_engine(emu.model, local_rank, args.precision).set_max_tile(args.max_tile)
         box = data.cpu().numpy()                       # pageable host memory, like np.random.randn(...) in README.md:84
-        res = emu.process_box(box, Z, OM, show_progress=False)             # first call: planning, workspace, pinned pool
-        del res
+        # two untimed calls: the first plans, allocates the workspace and pins the output arrays; a loop that rebinds
+        # `res` keeps the previous pair of fields alive during the next call, so the steady state cycles through two
+        # pinned pairs from the pool -- the second call pins the second pair (hipHostMalloc of 3.2 GB is not hot-path work)
+        res = emu.process_box(box, Z, OM, show_progress=False)
+        res = emu.process_box(box, Z, OM, show_progress=False)
         t0 = time.perf_counter()
         for _ in range(steps):
             res = emu.process_box(box, Z, OM, show_progress=False)

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -1680,7 +1681,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     const float* bd = (const float*)box;
     // Host arrays in and out, the whole periodic box as one tile in the z-slab schedule, pinned outputs: pipelined
     // (HostPipe).  Anything else: the box goes up in one piece before the first tile and the fields come down after the last.
-    static const bool pipe_off = getenv("NBE_HOST_PIPE") && atoi(getenv("NBE_HOST_PIPE")) == 0;
+    const bool pipe_off = getenv("NBE_HOST_PIPE") && atoi(getenv("NBE_HOST_PIPE")) == 0;   // read per call: A/B in one process
     auto& P = c->pipe;
     P.active = false;
     if (!in_dev && !out_dev && !order && !pipe_off && c->slab > 0 && c->pyx && c->pz && ndiv[0] * ndiv[1] * ndiv[2] == 1 &&
@@ -1735,10 +1736,16 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         HIPCHK(hipMemsetAsync(dd, 0, out_bytes, c->stream));
         if (c->vel) HIPCHK(hipMemsetAsync(vd, 0, out_bytes, c->stream));
     }
+    const bool trace = P.active && getenv("NBE_PIPE_TRACE") && atoi(getenv("NBE_PIPE_TRACE")) != 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_up0 = 0, t_range = 0, t_enq = 0;
     if (P.active) {
         // start the first upload, then reduce max|x| on the host while the DMA runs
         if (pipe_upload(c, 40, 40 + c->slab + 8)) return 1;
+        t_up0 = ms_since();
         if (prepare_range(c, nullptr, (int64_t)c->in_chan * S0 * S1 * S2, Dz, (const float*)box)) return 1;
+        t_range = ms_since();
     } else if (prepare_range(c, bd, (int64_t)c->in_chan * S0 * S1 * S2, Dz)) return 1;
     const int total = ndiv[0] * ndiv[1] * ndiv[2];
     const int n = order ? norder : total;
@@ -1760,8 +1767,15 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         if (c->vel) HIPCHK(hipMemcpyAsync(vel, vd, out_bytes, hipMemcpyDeviceToHost, c->stream));
     }
     if (!out_dev || !in_dev) {
-        if (P.active) { HIPCHK(hipStreamSynchronize(c->up_stream)); HIPCHK(hipStreamSynchronize(c->down_stream)); }
+        t_enq = ms_since();
         HIPCHK(hipStreamSynchronize(c->stream));
+        const double t_comp = ms_since();
+        if (P.active) { HIPCHK(hipStreamSynchronize(c->up_stream)); HIPCHK(hipStreamSynchronize(c->down_stream)); }
+        if (trace)
+            fprintf(stderr, "nbe pipe: first upload staged %.1f ms, max|x| on %d host threads %.1f ms, all work enqueued %.1f ms, "
+                            "kernels done %.1f ms, last slab on the host %.1f ms (input %s, outputs %s)\n",
+                    t_up0, host_threads(), t_range - t_up0, t_enq, t_comp, ms_since(), P.in_pinned ? "pinned" : "pageable",
+                    P.out_async ? "pinned" : "pageable");
         return check_range(c);                                  // host arrays: the call is synchronous anyway
     }
     return 0;

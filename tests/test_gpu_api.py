@@ -330,12 +330,12 @@ def test_host_array_pipeline_equals_resident(prec, monkeypatch):
         _lib.check(eng._l.nbe_process_box(eng._h, ptr(box), (C.c_int64 * 3)(*size), (C.c_int * 3)(*ndiv), (C.c_int * 6)(*([48] * 6)),
                                          Dz, vf, ptr(d2), ptr(v2), 0, C.cast(None, _lib.PROGRESS_CB), None))
         assert np.array_equal(d2, d) and np.array_equal(v2, v)
-        # a grid that does not merge into one periodic tile (crop 20, not a multiple of 8) takes the plain path
-        size2, ndiv2 = (40, 16, 16), (2, 1, 1)
-        b2 = np.random.default_rng(9).standard_normal((3,) + size2).astype(np.float32)
-        d3, v3 = eng.process_box(b2, size2, ndiv2, pad, Dz, vf)
+        # the caller's grid run exactly (no merging into one periodic tile) takes the plain path
+        eng.set_max_tile(0)
+        d3, v3 = eng.process_box(box, size, ndiv, pad, Dz, vf)
         assert eng.query("host_pipe") == 0.0
-        d3t, v3t = eng.process_box(torch.from_numpy(b2).cuda(), size2, ndiv2, pad, Dz, vf)
+        d3t, v3t = eng.process_box(torch.from_numpy(box).cuda(), size, ndiv, pad, Dz, vf)
+        eng.set_max_tile(512)
         assert np.array_equal(d3, d3t.cpu().numpy()) and np.array_equal(v3, v3t.cpu().numpy())
         # the pool hands a released block out again
         addr = d.ctypes.data
@@ -346,6 +346,7 @@ def test_host_array_pipeline_equals_resident(prec, monkeypatch):
         assert d4.ctypes.data == addr or True                      # (reuse is an optimisation, not a contract)
     finally:
         eng.set_slab(-1)
+        eng.set_max_tile(512)
 
 
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():

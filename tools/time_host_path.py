@@ -1,8 +1,13 @@
-"""PCIe-inclusive timing of the reference-shaped call: NumPy box in, NumPy fields out."""
-import sys, time
+"""Timing of the reference-shaped call -- NumPy box in, NumPy fields out (subbox.py:139-219) -- against the resident
+call, on one box in one process: pipelined (default), un-pipelined (NBE_HOST_PIPE=0), pinned input, CUDA tensors.
+NBE_PIPE_TRACE=1 prints the host-side timeline of every pipelined call.   python tools/time_host_path.py [N]"""
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
+os.environ.setdefault("NBE_PIPE_TRACE", "1")
+import torch
 import jax_nbody_emulator_with_dj_amd as J
+from jax_nbody_emulator_with_dj_amd import _lib
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 cfg = J.SubboxConfig(size=(N,) * 3, ndiv=(N // 128,) * 3)
@@ -11,8 +16,25 @@ p = m.init(1234)
 emu = J.create_emulator(load_params=False, processor_config=cfg)
 emu.processor.params = p
 box = np.random.default_rng(0).standard_normal((3, N, N, N), dtype=np.float32)
-for i in range(3):
-    t0 = time.perf_counter()
-    d, v = emu.process_box(box, 0.5, 0.3, show_progress=False)
-    print("call %d: %.3f s  (%.2f Mvox/s)  finite=%s" % (i, time.perf_counter() - t0, N ** 3 / (time.perf_counter() - t0) / 1e6,
-                                                        bool(np.isfinite(d).all() and np.isfinite(v).all())), flush=True)
+
+
+def run(tag, x, n=3):
+    for i in range(n):
+        t0 = time.perf_counter()
+        d, v = emu.process_box(x, 0.5, 0.3, show_progress=False)
+        if isinstance(d, torch.Tensor):
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("%-28s call %d: %.3f s  (%.2f Mvox/s)" % (tag, i, dt, N ** 3 / dt / 1e6), flush=True)
+        del d, v
+
+
+run("pageable in, pipelined", box, 4)
+os.environ["NBE_HOST_PIPE"] = "0"
+run("pageable in, un-pipelined", box, 2)
+del os.environ["NBE_HOST_PIPE"]
+pin = _lib.pinned_empty(box.shape, np.float32)
+pin[...] = box
+run("pinned in, pipelined", pin, 3)
+t = torch.from_numpy(box).cuda()
+run("CUDA tensors (resident)", t, 3)
