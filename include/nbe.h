@@ -100,7 +100,14 @@ enum { NBE_Q_GAUGE_ACTIVE = 0,     /* 1: the loaded weights run the two-product 
        NBE_Q_PERIODIC_Z = 3,       /* 1: ... and in z                                                                 */
        NBE_Q_RANGE_SHIFT = 4,      /* k of the last call's range shift 2^k                                            */
        NBE_Q_WORKSPACE_BYTES = 5,
-       NBE_Q_HOST_PIPE = 6 };      /* 1: the last nbe_process_box call ran the pipelined host path (nbe_host_alloc)    */
+       NBE_Q_HOST_PIPE = 6,        /* 1: the last nbe_process_box call ran the pipelined host path (nbe_host_alloc)    */
+       NBE_Q_GRAPH_REPLAYS = 7 };  /* tiles replayed from a captured hipGraph so far (see below)                       */
+/* hipGraph replay.  A tile of nbe_process_box / nbe_process_region with device pointers in and out enqueues a few
+ * hundred launches (the reference's analogue is the jitted step, subbox.py:137).  The second time the identical tile is
+ * requested -- same pointers, geometry, scalars, weights and modulation -- its schedule is captured (on the context's
+ * own stream, fenced against the caller's with events), and from the third time on it is ONE hipGraphLaunch.  Results
+ * are bit-identical to the eager schedule.  NBE_GRAPH=0 disables it; profiling, progress callbacks and the pipelined
+ * host path run eagerly. */
 int nbe_query(nbe_ctx* ctx, int what, double* out);
 
 /* replaces model.apply's `params` argument for the Style* cores (README.md:155; subbox.py:224-233) */

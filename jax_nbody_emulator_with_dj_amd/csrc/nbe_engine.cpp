@@ -158,6 +158,18 @@ struct nbe_ctx {
     char* stage_buf[NSTAGE] = {nullptr, nullptr, nullptr}; int64_t stage_bytes = 0;
     hipEvent_t stage_free[NSTAGE] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_up = nullptr, ev_down = nullptr;
+    // hipGraph replay of a tile's schedule (run_tile): everything a tile enqueues -- ~300 launches for the 512^3 box as
+    // one tile -- is captured the second time the same tile is asked for and replayed from then on
+    struct GraphKey {
+        const void *box, *disp, *velo, *ws;
+        int geo[18]; float f[3]; int epoch, flags;
+        bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof *this) < 0; }
+    };
+    struct GraphVal { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; int seen = 0; uint64_t used = 0; };
+    std::map<GraphKey, GraphVal> graphs;
+    uint64_t graph_clock = 0, graph_replays = 0;
+    int epoch = 0;                                // bumped whenever weights, modulation or schedule switches change
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
     // profiling
     bool prof = false;
     std::vector<ProfEntry> prof_entries;
@@ -301,8 +313,8 @@ static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
     const int gw = c->prec == PREC_F16 ? (C + 7) / 8 : c->prec == PREC_F16X3 ? 2 * ((C + 7) / 8) : (C + 3) / 4;
     if (!c->dry && t.off >= 0 && gw < t.p.G) {
         const size_t off = (size_t)gw * t.p.pstride * 4, bytes = (size_t)(t.p.G - gw) * t.p.pstride * 16;
-        (void)hipMemsetAsync(t.p.x + off, 0, bytes, c->stream);
-        if (t.p.dx) (void)hipMemsetAsync(t.p.dx + off, 0, bytes, c->stream);
+        launch_zero(t.p.x + off, (int64_t)bytes, c->stream);
+        if (t.p.dx) launch_zero(t.p.dx + off, (int64_t)bytes, c->stream);
     }
     return t;
 }
@@ -1000,10 +1012,77 @@ static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int 
     return 0;
 }
 
+static void drop_graphs(nbe_ctx* c) {
+    for (auto& kv : c->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    c->graphs.clear();
+}
+
+// One tile through run_subbox, replayed from a captured hipGraph when the identical tile (same pointers, geometry,
+// scalars, weights epoch) has been run before.  The first request runs eagerly on the caller's stream (one-time
+// hipFuncSetAttribute calls, lazily created state); the second is captured on the context's own stream -- the caller's
+// may be the legacy null stream, which cannot be captured -- and every later one is a single hipGraphLaunch, fenced
+// against the caller's stream by two events.  Not used with profiling, progress callbacks or the pipelined host path
+// (they synchronise or use other streams inside the schedule).  NBE_GRAPH=0 turns it off.
+static int run_tile(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0, int o1, int o2,
+                    int D, int H, int W, float Dz, float vel_fac, void* disp, void* velo, int out_dtype,
+                    int OD, int OH, int OW, int a0, int a1, int a2) {
+    const bool off = getenv("NBE_GRAPH") && atoi(getenv("NBE_GRAPH")) == 0;
+    if (off || c->prof || c->prog_cb || c->pipe.active || c->dry)
+        return run_subbox(c, box, Db, Hb, Wb, o0, o1, o2, D, H, W, Dz, vel_fac, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2);
+    nbe_ctx::GraphKey k;
+    memset(&k, 0, sizeof k);
+    k.box = box; k.disp = disp; k.velo = velo; k.ws = c->ws;
+    const int geo[18] = {Db, Hb, Wb, o0, o1, o2, D, H, W, out_dtype, OD, OH, OW, a0, a1, a2, c->slab, c->prec};
+    memcpy(k.geo, geo, sizeof geo);
+    k.f[0] = Dz; k.f[1] = vel_fac; k.f[2] = c->act_scale;
+    k.epoch = c->epoch; k.flags = (c->pyx ? 1 : 0) | (c->pz ? 2 : 0) | (c->gauge_active ? 4 : 0) | (c->fuse ? 8 : 0);
+    nbe_ctx::GraphVal& g = c->graphs[k];
+    g.used = ++c->graph_clock;
+    if (!g.exec && g.seen++ == 0) {                              // first time: eager
+        if (c->graphs.size() > 16) {                             // keep the cache small: drop the least recently used
+            auto lru = c->graphs.begin();
+            for (auto it = c->graphs.begin(); it != c->graphs.end(); ++it) if (it->second.used < lru->second.used) lru = it;
+            if (lru->second.exec) (void)hipGraphExecDestroy(lru->second.exec);
+            if (lru->second.graph) (void)hipGraphDestroy(lru->second.graph);
+            c->graphs.erase(lru);
+        }
+        return run_subbox(c, box, Db, Hb, Wb, o0, o1, o2, D, H, W, Dz, vel_fac, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2);
+    }
+    if (!c->ev_g0) { HIPCHK(hipEventCreateWithFlags(&c->ev_g0, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_g1, hipEventDisableTiming)); }
+    hipStream_t user = c->stream;
+    if (!g.exec) {                                               // second time: capture on the own stream
+        c->stream = c->own_stream;
+        hipError_t e = hipStreamBeginCapture(c->own_stream, hipStreamCaptureModeThreadLocal);
+        int rc = 0;
+        if (e == hipSuccess) {
+            rc = run_subbox(c, box, Db, Hb, Wb, o0, o1, o2, D, H, W, Dz, vel_fac, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2);
+            e = hipStreamEndCapture(c->own_stream, &g.graph);
+            if (e == hipSuccess && !rc) e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+        }
+        c->stream = user;
+        if (rc) return rc;
+        if (e != hipSuccess || !g.exec) {                        // capture is an optimisation: fall back to eager for good
+            (void)hipGetLastError();
+            if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+            g.exec = nullptr; g.seen = -1000000;
+            return run_subbox(c, box, Db, Hb, Wb, o0, o1, o2, D, H, W, Dz, vel_fac, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2);
+        }
+    }
+    if (user != c->own_stream) { HIPCHK(hipEventRecord(c->ev_g0, user)); HIPCHK(hipStreamWaitEvent(c->own_stream, c->ev_g0, 0)); }
+    HIPCHK(hipGraphLaunch(g.exec, c->own_stream));
+    if (user != c->own_stream) { HIPCHK(hipEventRecord(c->ev_g1, c->own_stream)); HIPCHK(hipStreamWaitEvent(user, c->ev_g1, 0)); }
+    ++c->graph_replays;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weights
 // ------------------------------------------------------------------------------------------------
 static void free_layers(nbe_ctx* c) {
+    drop_graphs(c); ++c->epoch;
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
@@ -1318,6 +1397,9 @@ int nbe_destroy(nbe_ctx* c) {
     prof_collect(c);
     free_layers(c);
     (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag); (void)hipFree(c->flags);
+    drop_graphs(c);
+    if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
+    if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < nbe_ctx::NSTAGE; ++i) { if (c->stage_buf[i]) (void)hipHostFree(c->stage_buf[i]); if (c->stage_free[i]) (void)hipEventDestroy(c->stage_free[i]); }
     if (c->ev_up) (void)hipEventDestroy(c->ev_up);
@@ -1406,6 +1488,7 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
     c->fuse = use_gauge && c->prec == PREC_F16X3;               // blocks with Layer::fskip run their skip inside conv_1
     HIPCHK(hipGetLastError());
     c->modulated = true; c->mod_Om = Om; c->mod_Dz = Dz;
+    ++c->epoch;                                                  // captured graphs hold the schedule of the previous modulation
     return 0;
 }
 
@@ -1755,7 +1838,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         // subbox.py:60-66: row-major over ndiv, last axis fastest
         const int a0 = (idx / (ndiv[1] * ndiv[2])) * c0, a1 = ((idx / ndiv[2]) % ndiv[1]) * c1, a2 = (idx % ndiv[2]) * c2;
         c->prog_cb = cb; c->prog_user = user; c->prog_k = k; c->prog_n = n;
-        if (run_subbox(c, bd, S0, S1, S2, (int)origin[0] + a0 - 48, (int)origin[1] + a1 - hal, (int)origin[2] + a2 - hal,
+        if (run_tile(c, bd, S0, S1, S2, (int)origin[0] + a0 - 48, (int)origin[1] + a1 - hal, (int)origin[2] + a2 - hal,
                        D, H, W, Dz, vel_fac, dd, vd, out_dtype, O0, O1, O2,
                        (int)oorigin[0] + a0, (int)oorigin[1] + a1, (int)oorigin[2] + a2)) return 1;
         if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb((k + 1) * 1000, n * 1000, user); }
@@ -1861,6 +1944,7 @@ int nbe_query(nbe_ctx* c, int what, double* out) {
     case NBE_Q_RANGE_SHIFT: *out = std::log2((double)c->act_scale); break;
     case NBE_Q_WORKSPACE_BYTES: *out = (double)c->ws_bytes; break;
     case NBE_Q_HOST_PIPE: *out = c->last_piped ? 1 : 0; break;
+    case NBE_Q_GRAPH_REPLAYS: *out = (double)c->graph_replays; break;
     default: return fail("nbe_query: unknown item %d", what);
     }
     return 0;
@@ -1937,10 +2021,26 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         int64_t bi, bo;
         Planes pin = mk(cin, D, H, W, &bi), pout = mk(cout, OD, OH, OW, &bo), pres = pout;
         const int64_t tot = 2 * bi + 4 * bo + ((int64_t)2 * H * W + 2 * W + 1024) * 16;
-        TCHK(hipMalloc((void**)&ws, tot)); TCHK(hipMemsetAsync(ws, 0, tot, c->stream));
-        pin.x = (float*)ws; pin.dx = (float*)(ws + bi);
-        pout.x = (float*)(ws + 2 * bi); pout.dx = (float*)(ws + 2 * bi + bo);
-        pres.x = (float*)(ws + 2 * bi + 2 * bo); pres.dx = (float*)(ws + 2 * bi + 3 * bo);
+        // NBE_TEST_ADDR_BIT31 = 0 / 1 places the tensors where bit 31 of their addresses is clear / set.  The global -> LDS
+        // DMA of the 16x16x32 kernels splits its wave-uniform base into two 32-bit halves (readfirstlane) and joins them
+        // again (dma16s); a join that sign-extends the low half is wrong exactly when that bit is set -- the memory access
+        // fault at 0xffffbf6e4000 of round 1 -- and right for every other address.
+        char* wb = nullptr;
+        if (const char* e = getenv("NBE_TEST_ADDR_BIT31")) {
+            const uint64_t two = 1ull << 31, want = atoi(e) ? 1 : 0;
+            if ((uint64_t)tot >= two) { rc = fail("NBE_TEST_ADDR_BIT31 needs a test tensor below 2 GiB"); break; }
+            TCHK(hipMalloc((void**)&ws, tot + 2 * two));
+            uint64_t b = ((uint64_t)ws + two - 1) & ~(two - 1);
+            if (((b >> 31) & 1) != want) b += two;
+            wb = (char*)b;
+        } else {
+            TCHK(hipMalloc((void**)&ws, tot));
+            wb = ws;
+        }
+        TCHK(hipMemsetAsync(wb, 0, tot, c->stream));
+        pin.x = (float*)wb; pin.dx = (float*)(wb + bi);
+        pout.x = (float*)(wb + 2 * bi); pout.dx = (float*)(wb + 2 * bi + bo);
+        pres.x = (float*)(wb + 2 * bi + 2 * bo); pres.dx = (float*)(wb + 2 * bi + 3 * bo);
         launch_to_planes(dxin, cin, pin, false, 1.0f, c->prec, c->stream);
         if (has_dx) launch_to_planes(ddx, cin, pin, true, 1.0f, c->prec, c->stream);
         if (flags & F_RES) {

@@ -121,6 +121,8 @@ void launch_head(const Planes& y, const Planes& xin, int c0, int C, const HeadSc
 // *out_bits = max(*out_bits, bit pattern of |src[i]|) over n floats (non-negative floats order like their bit
 // patterns; a NaN or an infinity gives >= 0x7f800000)
 void launch_absmax(const float* src, int64_t n, unsigned* out_bits, hipStream_t s);
+// zero `bytes` (a multiple of 16) at a 16-byte aligned address
+void launch_zero(void* dst, int64_t bytes, hipStream_t s);
 // dst[i] = (src[i] + (src2 ? src2[i] : 0)) * f
 void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s, const float* src2 = nullptr);
 

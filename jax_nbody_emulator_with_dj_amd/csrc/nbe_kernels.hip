@@ -641,6 +641,21 @@ void launch_absmax(const float* src, int64_t n, unsigned* out_bits, hipStream_t 
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, src, (long)n, out_bits);
 }
 
+// zero `units` 16-byte units (a kernel rather than hipMemsetAsync: it also runs inside captured graphs, where the
+// schedule should consist of kernel nodes only)
+__global__ __launch_bounds__(256) void zero_kernel(f32x4* __restrict__ dst, long units) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += stride) dst[i] = z;
+}
+
+void launch_zero(void* dst, int64_t bytes, hipStream_t s) {
+    const long units = bytes / 16;
+    if (units <= 0) return;
+    const unsigned blocks = (unsigned)std::min<long>(4096, (units + 255) / 256);
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (f32x4*)dst, units);
+}
+
 __global__ void scale_kernel(const float* __restrict__ src, const float* __restrict__ src2, float* __restrict__ dst, int n, float f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (src[i] + (src2 ? src2[i] : 0.f)) * f;

@@ -349,6 +349,52 @@ def test_host_array_pipeline_equals_resident(prec, monkeypatch):
         eng.set_max_tile(512)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f32", "f16"])
+def test_graph_replay_is_identical(prec, monkeypatch):
+    """A tile's schedule is captured into a hipGraph the second time the identical tile is requested and replayed from
+    the third (include/nbe.h; the reference's analogue is the jitted step, subbox.py:137): bit-identical fields, and a
+    new cosmology, new scalars or other tensors never hit a stale graph."""
+    import torch
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    monkeypatch.setenv("NBE_PRECISION", prec)
+    m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
+    p = _synthetic(29, 8)
+    eng = get_engine(m, 0)
+    eng.ensure_params(p, False)
+    pad = ((48, 48),) * 3
+    Dz, vf = float(J.growth_factor(Z, OM)), float(J.vel_norm(Z, OM))
+    eng.set_cosmology(OM, Dz)
+    for size, ndiv, mt in (((64, 48, 56), (2, 1, 1), 512), ((32, 16, 24), (2, 1, 1), 0)):   # one periodic tile / two padded ones
+        eng.set_max_tile(mt)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(31 + size[0])
+        box = torch.randn((3,) + size, device="cuda", generator=gen)
+        out = (torch.zeros_like(box), torch.zeros_like(box))
+        monkeypatch.setenv("NBE_GRAPH", "0")
+        d0, v0 = (t.clone() for t in eng.process_box(box, size, ndiv, pad, Dz, vf, out=out))
+        monkeypatch.delenv("NBE_GRAPH")
+        n0 = eng.query("graph_replays")
+        for i in range(4):                                           # eager, capture + launch, replay, replay
+            out[0].zero_(); out[1].zero_()
+            d, v = eng.process_box(box, size, ndiv, pad, Dz, vf, out=out)
+            assert torch.equal(d, d0) and torch.equal(v, v0), (size, i)
+        tiles = 1 if mt else 2
+        assert eng.query("graph_replays") - n0 == 3 * tiles
+        # other scalars: a different graph (or an eager run), never the stale one
+        d2, v2 = eng.process_box(box, size, ndiv, pad, Dz, 2.0 * vf, out=(torch.zeros_like(box), torch.zeros_like(box)))
+        assert torch.equal(d2, d0) and torch.allclose(v2, 2.0 * v0, rtol=1e-5, atol=1e-6)
+        # another cosmology re-modulates the weights behind the same pointers: the epoch in the key keeps graphs apart
+        eng.set_cosmology(0.25, 0.9)
+        for i in range(3):
+            d3, v3 = eng.process_box(box, size, ndiv, pad, 0.9, vf, out=out)
+        monkeypatch.setenv("NBE_GRAPH", "0")
+        d4, v4 = eng.process_box(box, size, ndiv, pad, 0.9, vf, out=(torch.zeros_like(box), torch.zeros_like(box)))
+        monkeypatch.delenv("NBE_GRAPH")
+        assert torch.equal(d3, d4) and torch.equal(v3, v4) and not torch.equal(d3, d0)
+        eng.set_cosmology(OM, Dz)
+    eng.set_max_tile(512)
+
+
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():
     """BASELINE config 3: 512^3 box, ndiv=(4,4,4), compute_vel=True, production width, resident tensors.
     Size-independent property: the engine's default execution (merged tiles: four of 352 x 352 x 608 input when

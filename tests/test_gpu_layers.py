@@ -146,3 +146,33 @@ def test_leaky_relu_pins(eng):
     rtol = 2.0 ** -11 if eng.precision == "f16" else 1e-6          # stored as float16: half an ulp
     np.testing.assert_allclose(y[0, 0, 0, :5], [-0.02, -0.01, 0.0, 1.0, 2.0], rtol=rtol, atol=0)
     np.testing.assert_allclose(dy[0, 0, 0, :5], [0.01, 0.01, 0.01, 1.0, 1.0], rtol=rtol, atol=0)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_dma_addressing_with_bit31_of_the_address_set(engine_factory, prec, monkeypatch):
+    """The 16x16x32 kernels feed their global -> LDS DMA with a wave-uniform 64-bit base that is split into 32-bit halves
+    (pinned in SGPRs with readfirstlane) and joined again, plus a 32-bit per-lane offset (nbe_kernels_h3.hip: dma16s).
+    A join that sign-extends the LOW half is wrong exactly when bit 31 of the address is set -- the intermittent memory
+    access fault of round 1 (address 0xffffbf6e4000 = an address ending in 0xbf6e4000 with the upper word all ones; it
+    came and went with where the allocator put the arena).  NBE_TEST_ADDR_BIT31 places the test tensors on either side
+    of that bit: same results, bit for bit, and within the layer tolerance of the oracle."""
+    from oracle import layers as L
+    half = prec == "f16"
+    e = engine_factory(precision=prec)
+    rng = np.random.default_rng(99)
+    cin, cout = 32, 64
+    x, dx = _rand(rng, cin, 6, 20, 40), _rand(rng, cin, 6, 20, 40)
+    w = _rand(rng, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)
+    dw = _rand(rng, cout, cin, 3, 3, 3) / np.sqrt(cin * 27)
+    b = (0.05 * _rand(rng, cout)).astype(np.float32)
+    out = {}
+    for bit in ("0", "1"):
+        monkeypatch.setenv("NBE_TEST_ADDR_BIT31", bit)
+        out[bit] = e.test_layer("conv3", x, w, b, dx=dx, dw=dw, act=True)
+    monkeypatch.delenv("NBE_TEST_ADDR_BIT31")
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    y, dy = L.conv_layer_vel("conv3", _h(x, half).astype(np.float64), _h(dx, half).astype(np.float64),
+                             _h(w, half).astype(np.float64), _h(dw, half).astype(np.float64), b.astype(np.float64))
+    y, dy = L.leaky_relu_vel(y, dy)
+    _chk(out["1"][0], y, "conv3 bit31 y", half)
+    _chk(out["1"][1], dy, "conv3 bit31 dy", half)
