@@ -368,7 +368,8 @@ static void prof_collect(nbe_ctx* c) {
     c->pending.clear();
 }
 
-static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false) {
+static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false, bool up8 = false) {
+    if (up8) return "up_h3<8 parities,vel,dx>";
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
     char b[96];
     if (g6 && prec_is_half(pw.prec)) snprintf(b, sizeof b, "%s<%s,vel,dx>", pw.prec == PREC_F16 ? "conv_h1g" : (pw.cout_t == 16 ? "conv_h3n" : "conv_h3g"), m);
@@ -397,7 +398,7 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
     const PackedW& pw = (g6 && L.pwn.w && !no_narrow) ? L.pwn : L.pw;
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
-        pe = prof_entry(c, conv_name(pw, c->vel, has_dx, g6));
+        pe = prof_entry(c, conv_name(pw, c->vel, has_dx, g6, cl.set < 0));
         ea = get_event(c); eb = get_event(c);
         (void)hipEventRecord(ea, c->stream);
     }
@@ -409,7 +410,7 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
         c->pending.push_back({pe, ea, eb});
         // algorithmic FLOPs: 2*MAC over valid outputs; x3 with tangent (x2 when the input has no tangent, and for
         // the gauged form W.x, W.dx~)
-        const double nout = (double)cl.Dv * cl.Hv * cl.Wv;
+        const double nout = (double)cl.Dv * cl.Hv * cl.Wv * (cl.set < 0 ? 8.0 : 1.0);
         const int taps = L.kind == 0 ? 27 : L.kind == 2 ? 8 : 1;
         const double gemms = c->vel ? ((has_dx && !g6) ? 3.0 : 2.0) : 1.0;
         c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.cin * taps * gemms;
@@ -542,11 +543,14 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
     const int Hx = x.p.H - 2 * xcrop, Wx = x.p.W - 2 * xcrop;
     if (cat.p.D != 2 * x.p.D || cat.p.H - 2 * cat.pad != 2 * Hx || cat.p.W - 2 * cat.pad != 2 * Wx)
         return fail("internal: concat geometry mismatch in %s", name);
-    for (int p = 0; p < 8; ++p) {
+    // f16x3 with velocity and Cin <= 64: all eight parities in one launch (up_h3_kernel: the input is read once)
+    static const bool up8_off = getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0;          // A/B switch
+    const bool up8 = c->prec == PREC_F16X3 && c->vel && L->pw.cin_pad <= 64 && !up8_off;
+    for (int p = 0; p < (up8 ? 1 : 8); ++p) {
         ConvLaunch cl; cl.in = x.p; cl.in_off = ((int64_t)xcrop * x.p.W + xcrop);
         cl.Dv = x.p.D; cl.Hv = Hx; cl.Wv = Wx; cl.out = inner(cat);
         cl.out_g0 = c->mid / (c->prec == PREC_F16 ? 8 : 4); cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
-        cl.flags = F_ACT; cl.set = p;
+        cl.flags = F_ACT; cl.set = up8 ? -1 : p;
         if (run_conv(c, *L, cl, true)) return 1;
     }
     return 0;
@@ -2056,8 +2060,11 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         else if (kind == 1) { cl.in_off = ((int64_t)crop * H + crop) * W + crop; cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; rc = run_conv(c, L, cl, has_dx); }
         else if (kind == 2) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; rc = run_conv(c, L, cl, has_dx); }
         else {
-            for (int p = 0; p < 8 && !rc; ++p) {
-                ConvLaunch u = cl; u.Dv = D; u.Hv = H; u.Wv = W; u.osz = 2; u.oz = (p >> 2) & 1; u.oy = (p >> 1) & 1; u.ox = p & 1; u.set = p;
+            // as upblock(): one launch for all eight parities where up_h3_kernel applies
+            const bool up8 = c->prec == PREC_F16X3 && vel && has_dx && pw.cin_pad <= 64 && !(getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0);
+            for (int p = 0; p < (up8 ? 1 : 8) && !rc; ++p) {
+                ConvLaunch u = cl; u.Dv = D; u.Hv = H; u.Wv = W; u.osz = 2; u.oz = (p >> 2) & 1; u.oy = (p >> 1) & 1; u.ox = p & 1;
+                u.set = up8 ? -1 : p;
                 rc = run_conv(c, L, u, has_dx);
             }
         }

@@ -72,7 +72,7 @@ struct ConvLaunch {
     int osz = 1, oz = 0, oy = 0, ox = 0;   // output voxel = (z*osz+oz, y*osz+oy, x*osz+ox) in out geometry
     Planes res;              // residual (same geometry as out), used when flags & F_RES
     int flags = 0;
-    int set = 0;             // weight set (parity) index
+    int set = 0;             // weight set (parity) index; -1: all eight sets of an up-sampling layer in one launch (f16x3, velocity)
     const float* gout = nullptr;   // tangent gauge of the output (per cout), f16x3 kernels only
     const float* beta = nullptr;   // gauged input: two-product tangent with this per-cout factor (3x3x3 f16x3 only)
     const float* bias = nullptr;   // replaces the layer's own bias (a block's conv_1 with its skip fused: b_1 + b_s)

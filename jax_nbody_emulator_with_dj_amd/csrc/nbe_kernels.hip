@@ -248,8 +248,10 @@ int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, h
     ka.Ho = L.out.H; ka.Wo = L.out.W; ka.osz = L.osz; ka.oz = L.oz; ka.oy = L.oy; ka.ox = L.ox;
     ka.r = L.res.x; ka.dr = L.res.dx; ka.res_pstride = L.res.pstride;
     ka.bias = L.bias ? L.bias : pw.bias;
-    ka.w = pw.w + (size_t)L.set * pw.floats;
-    ka.dw = pw.dw ? pw.dw + (size_t)L.set * pw.floats : nullptr;
+    const int set = L.set < 0 ? 0 : L.set;
+    ka.up8 = L.set < 0 ? 1 : 0; ka.set_stride = (long)pw.floats * 4;
+    ka.w = pw.w + (size_t)set * pw.floats;
+    ka.dw = pw.dw ? pw.dw + (size_t)set * pw.floats : nullptr;
     ka.nchunk = pw.cin_pad / prec_ck(pw.prec, pw.mode);
     ka.cout_groups = prec_is_half(pw.prec) ? (pw.cout + 7) / 8 : (pw.cout + 3) / 4;
     ka.flags = L.flags;

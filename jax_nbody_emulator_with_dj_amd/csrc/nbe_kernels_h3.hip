@@ -375,6 +375,133 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2x up-sampling as ONE launch (f16x3, velocity)
+// ------------------------------------------------------------------------------------------------
+// StyleTransposeBase3DVel (style_layers_vel.py:234-269) is eight 1x1x1 GEMMs on the same input, one per output parity
+// (weight set p = 4 oz + 2 oy + ox).  Run as eight launches of conv_h3_kernel<MODE_FLAT1> the input is read eight
+// times and every launch writes every other 16-byte unit of the output rows: the two x parities of a row meet in
+// HBM as partial lines.  Here a workgroup keeps its 256 input positions x all Cin <= 64 channels (X and dX, hi and lo:
+// 128 KB) resident in LDS, streams the 8 x Cin/16 weight stages (8 KB each, double-buffered) and stores parity after
+// parity: the input is read once, and the partial lines of the x-parity pairs are written by the same workgroup
+// microseconds apart, where they merge in L2.  Same MFMA mapping and epilogue as conv_h3_kernel.
+constexpr int UP_XV = 256;                           // positions per workgroup
+constexpr int UP_XC = 2 * 4 * UP_XV;                 // units of one resident chunk: (X, dX) x 4 units x 256
+constexpr int UP_MAXCH = 4;                          // Cin <= 64
+constexpr int UP_WS = 2 * 4 * 64;                    // units of one weight stage: (W, dW) x 4 units x 64 couts
+constexpr int UP_WBASE = UP_MAXCH * UP_XC;
+constexpr int UP_LDS_UNITS = UP_WBASE + 2 * UP_WS;   // 9216 units = 147,456 B
+
+__global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
+    f32x4* lds = lds_h3;
+    const half8* L8 = (const half8*)lds_h3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int it = wave & 1, jq = wave >> 1;
+    const int tile = xcd_tile(blockIdx.x, a.ntiles);
+    const int ct = blockIdx.y;
+    const long q0 = (long)tile * UP_XV;
+    const int nchunk = a.nchunk, nstage = 8 * nchunk;
+    const long HW = (long)a.H * a.W;
+
+    // ---- resident activations: chunk c, tensor t, unit u (2 h + part), position v: lds[c * UP_XC + (t * 4 + u) * 256 + v]
+    // 32 wave-instructions per chunk, 4 per wave
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = wave + 8 * k;                       // 0..31: tensor (n >> 4), unit ((n >> 2) & 3), quarter (n & 3)
+            const int t = n >> 4, u = (n >> 2) & 3, qd = n & 3;
+            const long v = q0 + a.in_off + qd * 64 + lane;
+            const char* src = (const char*)(t ? a.dx : a.x) + (((long)c * 4 + u) * a.in_pstride + v) * 16;
+            dma16((const float*)src, lds + c * UP_XC + (t * 4 + u) * UP_XV + qd * 64);
+        }
+    }
+    // ---- weights: stage st = p * nchunk + c  ->  set p, chunk c: 256 units of W, 256 of dW (one wave-instruction each per wave)
+    auto dma_w = [&](int st) {
+        const int p = st / nchunk, c = st - p * nchunk;
+        const bool d = wave >= 4;
+        const int m = wave & 3;
+        const char* src = (const char*)(d ? a.dw : a.w) + (long)p * a.set_stride +
+                          (((long)ct * nchunk + c) * 256 + m * 64 + lane) * 16;
+        dma16((const float*)src, lds + UP_WBASE + (st & 1) * UP_WS + (d ? 256 : 0) + m * 64);
+    };
+    dma_w(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 ym[2], yc[2], dm[2], dc[2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ym[jt][e] = 0.f; yc[jt][e] = 0.f; dm[jt][e] = 0.f; dc[jt][e] = 0.f; }
+    };
+    zero_acc();
+    // this lane's two input positions -> (z, y, x) once; the output voxel of parity p follows by shifts
+    int pz[2], py[2], px[2];
+    bool ok[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const long q = q0 + jq * 64 + 32 * jt + li;
+        const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
+        const int yy = rem / a.W, xx = rem - yy * a.W;
+        ok[jt] = q < a.Q && xx < a.Wv && yy < a.Hv && z < a.Dv;
+        pz[jt] = z; py[jt] = yy; px[jt] = xx;
+    }
+
+    for (int st = 0; st < nstage; ++st) {
+        const int p = st / nchunk, c = st - p * nchunk;
+        if (st + 1 < nstage) dma_w(st + 1);
+        const half8* wb = L8 + UP_WBASE + (st & 1) * UP_WS;
+        const half8* xb = L8 + c * UP_XC;
+        const int wo = (2 * lh) * 64 + 32 * it + li;
+        const half8 wh = wb[wo], wl = wb[wo + 64], dwh = wb[256 + wo], dwl = wb[256 + wo + 64];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int xo = (2 * lh) * UP_XV + jq * 64 + 32 * jt + li;
+            const half8 xh = xb[xo], xl = xb[xo + UP_XV], dxh = xb[4 * UP_XV + xo], dxl = xb[4 * UP_XV + xo + UP_XV];
+            ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
+            yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, yc[jt], 0, 0, 0);
+            yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, yc[jt], 0, 0, 0);
+            dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xh, dm[jt], 0, 0, 0);
+            dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xl, dc[jt], 0, 0, 0);
+            dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwl, xh, dc[jt], 0, 0, 0);
+            dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxh, dm[jt], 0, 0, 0);
+            dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxl, dc[jt], 0, 0, 0);
+            dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dxh, dc[jt], 0, 0, 0);
+        }
+        if (c == nchunk - 1) {                               // parity p is complete: store it, start the next
+            long o[2];
+            bool okk[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                okk[jt] = ok[jt];
+                o[jt] = okk[jt] ? ((long)(2 * pz[jt] + ((p >> 2) & 1)) * a.Ho + (2 * py[jt] + ((p >> 1) & 1))) * a.Wo + (2 * px[jt] + (p & 1)) : 0;
+            }
+            h3_store2<true, true>(a, ct, it, lh, o, okk, ym, yc, dm, dc);
+            zero_acc();
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W(st + 1) has landed (stores included: they are few)
+        __syncthreads();
+    }
+}
+
+static int launch_up_h3(ConvKArgs ka, int ctiles, hipStream_t s) {
+    constexpr size_t smem = (size_t)UP_LDS_UNITS * 16;
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
+    if (ka.nchunk > UP_MAXCH) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)up_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
+    hipLaunchKernelGGL(up_h3_kernel, grid, block, smem, s, ka);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3x3x3 convolution on 2-D patches (the production kernel for MODE_FLAT3 layers)
 // ------------------------------------------------------------------------------------------------
 // The flat tiling above re-fetches every activation row segment once per (dz,dy) pair: 95 B of activation DMA
@@ -1780,6 +1907,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         else if (depth == 3) { NBE_VD(launch_h3_v, MODE_FLAT3, 3, true) }
         else { NBE_VD(launch_h3_v, MODE_FLAT3, 2, true) }
     } else if (pw.mode == MODE_FLAT1) {
+        if (ka.up8) return (split && vel && has_dx) ? launch_up_h3(ka, ct, s) : 1;      // all eight parities in one launch
         if (!split) { NBE_VD(launch_h3_v, MODE_FLAT1, 2, false) } else { NBE_VD(launch_h3_v, MODE_FLAT1, 2, true) }
     } else {
         if (!split) { NBE_VD(launch_h3_v, MODE_DOWN, 2, false) } else { NBE_VD(launch_h3_v, MODE_DOWN, 2, true) }

@@ -38,6 +38,7 @@ struct ConvKArgs {
     const float* xs; const float* dxs; long s_pstride; const float* xs2; const float* dxs2; long s2_pstride; int s_csplit;
     const float* ws; const float* dws; int nskip;
     long dws_delta;          // dws - ws in bytes
+    int up8; long set_stride; // up_h3_kernel: all eight parity sets of an up-sampling layer; bytes between weight sets
     ConvGroupSrc gs[NBE_MAX_GROUPS];
 };
 
