@@ -160,6 +160,24 @@ int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3],
                        float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
                        const int64_t out_size[3], const int64_t out_origin[3]);
 
+/* Brick mode of a sharded box (no reference counterpart: the reference is single-device).  The ranks of a node cut the
+ * periodic box into slabs along z; every rank holds its brick haloed by 48 planes of the raw input on either side
+ * ((C, b0 + 96, S1, S2), device memory) and is periodic in y and x by itself.  The network's z context below the
+ * full-resolution level -- 22 planes of the down_l0 output on either side, which padded bricks would recompute from 44
+ * more planes of level-0 work each -- is EXCHANGED between neighbours instead:
+ *   nbe_brick_encode   runs the level-0 encoder on the brick and writes its first / last 22 down_l0 planes to send_lo /
+ *                      send_hi (device buffers of nbe_brick_halo_bytes each; opaque 16-byte units);
+ *   (the caller sends send_lo to its z-minus neighbour and send_hi to its z-plus neighbour, and receives their send_hi /
+ *    send_lo as recv_lo / recv_hi -- torch.distributed P2P = RCCL over xGMI in jax_nbody_emulator_with_dj_amd/sharding.py)
+ *   nbe_brick_finish   runs levels 1-3 and the level-0 decoder and writes the brick's (C, b0, S1, S2) fields.
+ * Both calls are asynchronous on the context's stream.  The result is bit-identical to the single-device
+ * nbe_process_box of the whole box.  b0 must be a multiple of 8 and at least 44. */
+int64_t nbe_brick_halo_bytes(nbe_ctx* ctx, const int64_t brick_size[3]);
+int nbe_brick_encode(nbe_ctx* ctx, const void* haloed_brick, const int64_t brick_size[3], float Dz, float vel_fac,
+                     void* send_lo, void* send_hi);
+int nbe_brick_finish(nbe_ctx* ctx, const void* recv_lo, const void* recv_hi, float Dz, float vel_fac,
+                     void* disp, void* vel, int out_dtype);
+
 /* Internal tiling.  When crop_size = size/ndiv is a multiple of 8 on every axis, all crop origins keep the
  * phase of the network's 2^3 stride lattice, so the per-voxel result does not depend on how the box is cut
  *  and neighbouring sub-boxes can be merged into larger tiles that recompute less halo

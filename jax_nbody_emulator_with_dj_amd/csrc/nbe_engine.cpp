@@ -115,6 +115,19 @@ struct nbe_ctx {
     bool pyx = false;                             // current tile runs in periodic-yx mode (it spans the periodic box in y and x)
     bool pyx_allowed = true;                      // env NBE_PERIODIC=0 turns the mode off
     bool pz = false;                              // ... and the tile also spans the box in z (only with pyx)
+    // Brick mode of the sharded box (nbe_brick_encode / nbe_brick_finish): the tile is one rank's z-slab of the periodic
+    // box, periodic in y and x; in z it runs like pz, except that the 22 planes of level-1 context on either side are
+    // the neighbours' down_l0 outputs, exchanged between the two calls, instead of periodic wrap-around.
+    bool zx = false;
+    int phase = 0;                                // 0: whole schedule; 1: up to the exchange; 2: from the exchange on
+    struct BrickIO { void *send_lo = nullptr, *send_hi = nullptr; const void *recv_lo = nullptr, *recv_hi = nullptr; } bio;
+    struct StreamState {                          // what phase 2 resumes with (handles into the arena, which is left alone in between)
+        bool valid = false;
+        int64_t skip0_off = -1, td_off = -1, tin_off = -1;
+        Planes skip0, td, tin; int skip0_pad = 0, tin_pad = 0;
+        int D = 0, H = 0, W = 0, S = 0;
+        std::vector<Arena::Blk> blks; int64_t high = 0;
+    } sst;
     // progress inside a tile (z-slab schedule): tile k of n, reported in thousandths of a tile
     nbe_progress_cb prog_cb = nullptr; void* prog_user = nullptr; int prog_k = 0, prog_n = 1;
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
@@ -792,7 +805,23 @@ static int pipe_output(nbe_ctx* c, int z, int n) {
 // 48-voxel periodic padding, without computing the halo voxels (about 10 % of the FLOPs of a 512^3 box).  The levels
 // below keep the padded scheme: down_l0 runs on the interior and its output is extended periodically by the 22
 // voxels of context those levels consume; up_r0 takes the centre of the level-1 result.
-static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S) {
+// 22 planes of down_l0 output in an exchange buffer: [x planes][dx planes], each G plane groups of 22 x H x W units
+static constexpr int BRICK_HALO = 22;
+static Planes brick_planes(nbe_ctx* c, const Tensor& td, const void* buf) {
+    Planes p = td.p;
+    p.D = BRICK_HALO;
+    p.pstride = (p.vox() + 63) & ~int64_t(63);
+    p.x = (float*)buf;
+    p.dx = c->vel ? (float*)buf + (int64_t)p.G * p.pstride * 4 : nullptr;
+    return p;
+}
+static int64_t brick_halo_bytes(nbe_ctx* c, int Hd, int Wd) {
+    Planes p; p.G = planes_for(c->mid, c->prec); p.D = BRICK_HALO; p.H = Hd; p.W = Wd;
+    p.pstride = (p.vox() + 63) & ~int64_t(63);
+    return (int64_t)p.G * p.pstride * 16 * (c->vel ? 2 : 1);
+}
+
+static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, Tensor* skip0_out, Tensor* td_out) {
     const int m = c->mid, pad = tin.pad;
     const int D = tin.p.D, H = tin.p.H, W = tin.p.W;
     const int Hi = H - 2 * pad, Wi = W - 2 * pad;
@@ -800,7 +829,8 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     // Periodic in z too (the tile is the whole box): the 40 outermost planes of the level-0 encoder output on either
     // side only feed the lower levels, whose input can be extended periodically in z just as in y and x.  The encoder
     // then produces the Y - 80 planes of the skip connection only, and down_l0 the box's own (D - 96) / 2 planes.
-    const bool pz = pad && c->pz;
+    const bool zx = pad && c->zx;                                 // brick mode: as pz, the z context of level 1 comes from the neighbours
+    const bool pz = pad && (c->pz || zx);
     const int zlo = pz ? 40 : 0, zhi = pz ? Y - 40 : Y;
     // the level-0 skip connection: centre crop by 40 (z only in periodic-yx mode)
     Tensor skip0 = pad ? tallocp(c, m, Y - 80, Hi, Wi, pad) : talloc(c, m, Y - 80, H - 88, W - 88);
@@ -856,6 +886,21 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     }
     tfree(c, h0); tfree(c, a); tfree(c, h1);
     if (!pz) tfree(c, y0r);
+    *skip0_out = skip0; *td_out = td;
+    return 0;
+}
+
+// Everything after the level-0 encoder: levels 1-3, then the level-0 decoder slab by slab with the head.
+static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, Tensor skip0, Tensor td) {
+    const int m = c->mid, pad = tin.pad;
+    const int D = tin.p.D, H = tin.p.H, W = tin.p.W;
+    const int Hi = H - 2 * pad, Wi = W - 2 * pad;
+    const bool zx = pad && c->zx;
+    const bool pz = pad && (c->pz || zx);
+    const int sy = pad ? 0 : 2;
+    const Layer *Lr00 = find_layer(c, "conv_r00", "conv_1"), *Lr01 = find_layer(c, "conv_r01", "conv_1");
+    if (!Lr00 || !Lr01) return fail("missing conv_1 layers of the level-0 blocks");
+    (void)D; (void)Hi; (void)Wi;
     // Level 1.  Periodic-yx: it runs periodic in y and x as well -- its input is the interior result of down_l0 with a
     // 1-voxel wrap-around halo (and, periodic in z, 22 planes of periodic context); level 2 and below keep the padded
     // scheme: down_l1 runs on the interior and is extended periodically by the 10 voxels those levels consume.
@@ -863,7 +908,12 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     if (pad) {
         t = tallocp(c, m, td.p.D + (pz ? 44 : 0), td.p.H, td.p.W, 1);
         if (t.off < 0) return fail("workspace exhausted (level 1 input)");
-        if (!c->dry) launch_wrap_pad(td.p, t.p, 1, c->vel, c->stream, pz ? 22 : 0);
+        if (zx && !c->dry) {
+            // brick: own planes in the middle, the neighbours' boundary planes (received between the two calls) around them
+            launch_wrap_pad(td.p, zview(t, 22, td.p.D).p, 1, c->vel, c->stream, 0);
+            launch_wrap_pad(brick_planes(c, td, c->bio.recv_lo), zview(t, 0, 22).p, 1, c->vel, c->stream, 0);
+            launch_wrap_pad(brick_planes(c, td, c->bio.recv_hi), zview(t, 22 + td.p.D, 22).p, 1, c->vel, c->stream, 0);
+        } else if (!c->dry) launch_wrap_pad(td.p, t.p, 1, c->vel, c->stream, pz ? 22 : 0);
         tfree(c, td);
     }
 
@@ -954,6 +1004,33 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     tfree(c, cat); tfree(c, hq); tfree(c, q); tfree(c, hy); tfree(c, y);
     tfree(c, r); tfree(c, skip0);
     return 0;
+}
+
+static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S) {
+    Tensor skip0, td;
+    auto& st = c->sst;
+    if (c->phase != 2) {
+        if (stream_encode(c, tin, ho, S, &skip0, &td)) return 1;
+        if (c->phase == 1) {
+            // brick mode, first call: hand the boundary planes of the down_l0 output to the caller and stop; the arena
+            // keeps the skip connection, the down_l0 output and the input tensor until nbe_brick_finish resumes
+            if (!c->dry) {
+                launch_crop(zview(td, 0, BRICK_HALO).p, 0, brick_planes(c, td, c->bio.send_lo), 0, c->vel, c->stream, 0);
+                launch_crop(zview(td, td.p.D - BRICK_HALO, BRICK_HALO).p, 0, brick_planes(c, td, c->bio.send_hi), 0, c->vel, c->stream, 0);
+            }
+            st.valid = true; st.skip0 = skip0.p; st.skip0_off = skip0.off; st.skip0_pad = skip0.pad;
+            st.td = td.p; st.td_off = td.off; st.tin = tin.p; st.tin_off = tin.off; st.tin_pad = tin.pad; st.S = S;
+            st.blks = c->arena.blks; st.high = c->arena.high;
+            return 0;
+        }
+    } else {
+        if (!st.valid) return fail("nbe_brick_finish without a preceding nbe_brick_encode");
+        skip0.p = st.skip0; skip0.off = st.skip0_off; skip0.pad = st.skip0_pad;
+        td.p = st.td; td.off = st.td_off;
+        c->arena.blks = st.blks; c->arena.high = st.high;
+        st.valid = false;
+    }
+    return stream_rest(c, tin, ho, S, skip0, td);
 }
 
 // periodic-yx tiles: z as usual; y and x are the box itself (+ 2 halo voxels), a multiple of 8 with room for the
@@ -1923,6 +2000,67 @@ int nbe_host_trim(void) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (auto& kv : g_pin_free) (void)hipHostFree(kv.second);
     g_pin_free.clear(); g_pin_free_bytes = 0;
+    return 0;
+}
+
+// ---- brick mode: one rank's z-slab of a periodic box, level-1 context exchanged instead of recomputed ---------------
+static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* W) {
+    if (require_ready(c)) return 1;
+    if (!bsize) return fail("null argument");
+    const int64_t b0 = bsize[0], S1 = bsize[1], S2 = bsize[2];
+    if (b0 % 8 != 0 || b0 / 2 < BRICK_HALO) return fail("brick depth %lld unsupported: a multiple of 8, at least %d", (long long)b0, 2 * BRICK_HALO);
+    *D = (int)b0 + 96; *H = (int)S1 + 2; *W = (int)S2 + 2;
+    if (check_dims_pyx(*D, *H, *W)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    c->pyx = true; c->pz = false; c->zx = true;
+    const int64_t budget = plan_budget(c, 0);
+    int64_t need = 0;
+    const int sl = choose_slab(c, *D, *H, *W, budget < 0 ? INT64_MAX / 4 : budget, &need, true, false);
+    if (sl <= 0) { c->zx = false; return fail("brick of %lld x %lld x %lld does not fit the device memory that is free", (long long)b0, (long long)S1, (long long)S2); }
+    c->slab = sl; c->pyx = true; c->pz = false;
+    return 0;
+}
+
+int64_t nbe_brick_halo_bytes(nbe_ctx* c, const int64_t bsize[3]) {
+    if (!c || !bsize) return -1;
+    return brick_halo_bytes(c, (int)bsize[1] / 2, (int)bsize[2] / 2);
+}
+
+int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float Dz, float vel_fac, void* send_lo, void* send_hi) {
+    if (!c || !box || !send_lo || !send_hi) return fail("null argument");
+    if (!is_device_ptr(box) || !is_device_ptr(send_lo) || !is_device_ptr(send_hi)) return fail("nbe_brick_encode takes device pointers");
+    int D, H, W;
+    if (brick_setup(c, bsize, &D, &H, &W)) return 1;
+    struct Off { nbe_ctx* c; ~Off() { c->phase = 0; c->zx = false; } } off{c};
+    if (ensure_workspace(c, D, H, W)) return 1;
+    if (prepare_range(c, (const float*)box, (int64_t)c->in_chan * D * bsize[1] * bsize[2], Dz)) return 1;
+    c->arena.reset();
+    Tensor tin = talloc(c, c->in_chan, D, H, W);
+    tin.pad = 1;
+    // the haloed brick is (C, b0 + 96, S1, S2): z as it is (the halo planes are there), y and x periodic (origin -1)
+    launch_gather((const float*)box, c->in_chan, D, (int)bsize[1], (int)bsize[2], 0, -1, -1, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
+    c->phase = 1; c->bio.send_lo = send_lo; c->bio.send_hi = send_hi;
+    c->sst.D = D; c->sst.H = H; c->sst.W = W;
+    const HeadOut ho{nullptr, nullptr, NBE_F32, (int)bsize[0], (int)bsize[1], (int)bsize[2], 0, 0, 0, Dz, vel_fac};
+    if (network_stream(c, tin, ho, c->slab)) return 1;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int nbe_brick_finish(nbe_ctx* c, const void* recv_lo, const void* recv_hi, float Dz, float vel_fac, void* disp, void* vel, int out_dtype) {
+    if (!c || !recv_lo || !recv_hi || !disp) return fail("null argument");
+    if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
+    if (!c->sst.valid) return fail("nbe_brick_finish without a preceding nbe_brick_encode");
+    if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
+    HIPCHK(hipSetDevice(c->device));
+    c->pyx = true; c->pz = false; c->zx = true; c->phase = 2;
+    struct Off { nbe_ctx* c; ~Off() { c->phase = 0; c->zx = false; } } off{c};
+    c->bio.recv_lo = recv_lo; c->bio.recv_hi = recv_hi;
+    Tensor tin; tin.p = c->sst.tin; tin.off = c->sst.tin_off; tin.pad = c->sst.tin_pad;
+    const int b0 = c->sst.D - 96, S1 = c->sst.H - 2, S2 = c->sst.W - 2;
+    const HeadOut ho{disp, vel, out_dtype, b0, S1, S2, 0, 0, 0, Dz, vel_fac};
+    if (network_stream(c, tin, ho, c->sst.S)) return 1;
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -290,6 +290,25 @@ class Engine:
                                          oarr, 0 if order is None else len(order), float(Dz), float(vel_fac),
                                          _ptr(disp), _ptr(vel), 1 if half else 0, i64(disp.shape[1:]), i64(out_origin)))
 
+    # ---- brick mode (sharded box, z-slabs with one activation exchange per box) -------------------
+    def brick_halo_bytes(self, bshape):
+        n = int(self._l.nbe_brick_halo_bytes(self._h, (C.c_int64 * 3)(*[int(v) for v in bshape])))
+        if n < 0:
+            raise NBEError("nbe_brick_halo_bytes failed")
+        return n
+
+    def brick_encode(self, haloed, bshape, Dz, vel_fac, send_lo, send_hi):
+        """haloed: CUDA tensor (C, b0 + 96, S1, S2); send_lo / send_hi: CUDA uint8 tensors of brick_halo_bytes()."""
+        self._follow_torch_stream(haloed)
+        check(self._l.nbe_brick_encode(self._h, _ptr(haloed), (C.c_int64 * 3)(*[int(v) for v in bshape]), float(Dz),
+                                       float(vel_fac), _ptr(send_lo), _ptr(send_hi)))
+
+    def brick_finish(self, recv_lo, recv_hi, Dz, vel_fac, disp, vel):
+        self._follow_torch_stream(disp)
+        half = disp.element_size() == 2
+        check(self._l.nbe_brick_finish(self._h, _ptr(recv_lo), _ptr(recv_hi), float(Dz), float(vel_fac), _ptr(disp),
+                                       _ptr(vel), 1 if half else 0))
+
     # ---- test hooks ---------------------------------------------------------------------------
     def test_layer(self, kind, x, w, bias, dx=None, dw=None, crop=0, act=False, res=None, dres=None):
         kinds = {'conv3': 0, 'skip': 1, 'down': 2, 'up': 3}

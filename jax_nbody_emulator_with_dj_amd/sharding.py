@@ -11,6 +11,18 @@ are replicated and outputs stay in the owning rank's brick.
 The exchange is axis by axis (3 rounds, 2 messages per split axis) so that edges and
 corners arrive through the face messages: the slab sent along axis a spans the halos
 already filled on axes < a.  Bytes per rank for 512^3 on a 2x2x2 grid: 322 MB.
+
+z-slab bricks (rank grid (N,1,1), the default whenever a slab is at least 44 planes deep).
+A brick that is not split in y and x is periodic there by itself, so only its z halo costs
+anything -- and most of that cost sits BELOW the full-resolution level: the 48-plane halo of
+the raw input exists to give levels 1-3 their 22 planes of context.  Instead of recomputing
+44 planes of level-0 work per side for it, the ranks exchange the 22 boundary planes of the
+down_l0 OUTPUT once per box (Engine.brick_encode -> P2P -> Engine.brick_finish; 738 MB per
+direction for 512^3 on 8 ranks, a few ms over xGMI against ~0.25 s of compute).  What is
+still recomputed is the level-0 halo of 4 + 4 planes (the skip connection's receptive field)
+and the 22-plane halo at level 1 (1/8 of the work per plane): 1.25 x the work of the ideal
+at 8 ranks instead of 1.45 x with 256^3 bricks.  Fields are bit-identical to the single-GPU
+run.  The four exchange buffers are allocated once per ShardedBox.
 """
 
 import numpy as np
@@ -25,23 +37,36 @@ except Exception:  # pragma: no cover
 PAD = 48
 
 
+BRICK_MIN_DEPTH = 44          # two times the 22 planes of level-1 context a brick hands to each neighbour
+
+
+def _zbrick_factor(e0):
+    """Work per output voxel of a z-slab brick of depth e0 with the level-1 exchange, relative to no halo at all:
+    level 0 (90 % of the FLOPs) computes ~7 extra planes, level 1 (8.5 %) 44 extra half-resolution planes, levels 2-3
+    (1.5 %) about as many again."""
+    return 1.0 + 0.90 * 7.0 / e0 + 0.085 * 44.0 / (e0 / 2.0) + 0.015 * 44.0 / (e0 / 2.0)
+
+
 def _halo_factor(e):
     """Work per output voxel of a padded axis of extent e relative to an axis without halo recompute (fit to the
     measured 17.1 / 11.2 / 9.33 MFLOP per voxel of 128^3 / 256^3 / 512^3 tiles against the network's 7.93)."""
     return 1.0 + 30.0 / e + 900.0 / (e * e)
 
 
-def rank_grid(world_size, ndiv, size=None, pad=PAD):
+def rank_grid(world_size, ndiv, size=None, pad=PAD, zbricks=True):
     """Split `world_size` ranks over the sub-box grid `ndiv`: the factorisation with the least halo recompute.
     A brick that is not split in y and x runs the engine's periodic mode there and pays only for its z halo;
-    otherwise every axis pays its padded factor.  512^3 / ndiv 4: 2 -> (2,1,1), 4 -> (4,1,1) (measured on one card:
-    0.84 s per brick against 0.92 s for (2,2,1)), 8 -> (2,2,2), 16 -> (4,2,2).  Ties go to the leading axes."""
+    otherwise every axis pays its padded factor.  z-slab bricks of at least 44 planes exchange their level-1 context
+    instead of recomputing it (zbricks, see the module docstring).  512^3 / ndiv 4: 2 -> (2,1,1), 4 -> (4,1,1),
+    8 -> (8,1,1) when the sub-box grid allows it, else (2,2,2); the sub-box grid only has to be divisible by the rank
+    grid in y and x (along z a rank takes its slab as one tile).  Ties go to the leading axes."""
     n = int(world_size)
     if size is None:
         size = tuple(128 * d for d in ndiv)
     best, best_cost = None, None
     for g0 in range(1, n + 1):
-        if n % g0 or ndiv[0] % g0:
+        zslab_ok = zbricks and size[0] % g0 == 0 and (size[0] // g0) % 8 == 0 and size[0] // g0 >= BRICK_MIN_DEPTH
+        if n % g0 or (ndiv[0] % g0 and not (zslab_ok and g0 == n)):
             continue
         for g1 in range(1, n // g0 + 1):
             if (n // g0) % g1 or ndiv[1] % g1:
@@ -53,7 +78,10 @@ def rank_grid(world_size, ndiv, size=None, pad=PAD):
             if any(g > 1 and ee < pad for g, ee in zip((g0, g1, g2), e)):
                 continue                                  # a brick must hold its neighbour's halo
             if g1 == 1 and g2 == 1:
-                cost = _halo_factor(e[0]) if g0 > 1 else 1.0
+                if g0 > 1 and e[0] >= BRICK_MIN_DEPTH and e[0] % 8 == 0 and zbricks:
+                    cost = _zbrick_factor(e[0])               # level-1 context exchanged, not recomputed
+                else:
+                    cost = _halo_factor(e[0]) if g0 > 1 else 1.0
             else:
                 cost = _halo_factor(e[0]) * _halo_factor(e[1]) * _halo_factor(e[2])
             key = (round(cost, 6), -g0, -g1)
@@ -151,19 +179,65 @@ def split_interior(nd_local, bshape, pad=PAD):
     return interior, boundary
 
 
+def exchange_z_faces(send_lo, send_hi, recv_lo, recv_hi, coords, grid, group=None):
+    """Boundary planes of the z-slab bricks: my low planes become the high halo of my z-minus neighbour, my high planes
+    the low halo of my z-plus neighbour (periodic).  Tensors of equal size, CUDA with nccl (= RCCL: device to device
+    over xGMI) or CPU / CUDA with gloo (CUDA tensors are staged through the host: test rigs with several ranks per GPU)."""
+    if grid[0] == 1:                                           # one brick: its own periodic images
+        recv_hi.copy_(send_lo)
+        recv_lo.copy_(send_hi)
+        return
+    cm, cp = list(coords), list(coords)
+    cm[0] -= 1
+    cp[0] += 1
+    minus, plus = coords_rank(cm, grid), coords_rank(cp, grid)
+    stage = send_lo.is_cuda and dist.get_backend(group) == "gloo"
+    s_lo, s_hi = (send_lo.cpu(), send_hi.cpu()) if stage else (send_lo, send_hi)
+    r_hi, r_lo = (torch.empty_like(s_lo), torch.empty_like(s_hi)) if stage else (recv_hi, recv_lo)
+    # order discipline (P2P between one pair matches in order; minus == plus when grid[0] == 2):
+    # sends (1) low -> minus, (2) high -> plus ; receives (1) high halo <- plus, (2) low halo <- minus
+    ops = [dist.P2POp(dist.isend, s_lo, minus, group), dist.P2POp(dist.isend, s_hi, plus, group),
+           dist.P2POp(dist.irecv, r_hi, plus, group), dist.P2POp(dist.irecv, r_lo, minus, group)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if stage:
+        recv_hi.copy_(r_hi)
+        recv_lo.copy_(r_lo)
+
+
 class ShardedBox:
     """One rank's share of a periodic box: brick resident on this rank's GPU."""
 
-    def __init__(self, engine, size, ndiv, rank, world_size, group=None, comm_stream=None):
+    def __init__(self, engine, size, ndiv, rank, world_size, group=None, comm_stream=None, zbricks=None):
+        import os
         self.eng = engine
         self.size, self.ndiv = tuple(size), tuple(ndiv)
         self.rank, self.world = rank, world_size
-        self.grid = rank_grid(world_size, ndiv, self.size)
+        if zbricks is None:
+            zbricks = os.environ.get("NBE_ZBRICKS", "1") != "0"
+        # the brick mode computes every voxel of the box: only where the reference's sub-boxes do (no remainder) and where
+        # cutting the box differently gives the same field (crop % 8 == 0, SURVEY 7.2)
+        exact = all(s % n == 0 and (s // n) % 8 == 0 for s, n in zip(self.size, self.ndiv))
+        self.grid = rank_grid(world_size, ndiv, self.size, zbricks=zbricks and exact)
         self.coords = rank_coords(rank, self.grid)
         self.origin, self.bshape = brick_extent(self.coords, self.grid, size)
-        self.nd_local = local_ndiv(ndiv, self.grid)
+        self.zbricks = (zbricks and exact and self.grid[1] == 1 and self.grid[2] == 1 and self.bshape[0] % 8 == 0
+                        and self.bshape[0] >= BRICK_MIN_DEPTH and self.bshape[1] >= 48 and self.bshape[2] >= 48)
+        self.nd_local = tuple(max(1, n // g) for n, g in zip(ndiv, self.grid))
         self.group = group
         self.comm_stream = comm_stream
+        self._halo = None                       # (send_lo, send_hi, recv_lo, recv_hi), allocated once
+
+    def _process_zbrick(self, brick, Dz, vel_fac, disp, vel):
+        """z-slab brick with ONE exchange of level-1 activations (module docstring)."""
+        H = exchange_halo(brick, self.grid, self.coords, PAD, self.group, pad_unsplit=False)     # raw input, 48 planes in z
+        if self._halo is None or self._halo[0].device != brick.device:
+            n = self.eng.brick_halo_bytes(self.bshape)
+            self._halo = tuple(torch.empty(n, dtype=torch.uint8, device=brick.device) for _ in range(4))
+        s_lo, s_hi, r_lo, r_hi = self._halo
+        self.eng.brick_encode(H, self.bshape, Dz, vel_fac, s_lo, s_hi)
+        exchange_z_faces(s_lo, s_hi, r_lo, r_hi, self.coords, self.grid, self.group)
+        self.eng.brick_finish(r_lo, r_hi, Dz, vel_fac, disp, vel)
 
     def process(self, brick, Dz, vel_fac, disp, vel, check_finite=True):
         """brick, disp, vel: CUDA tensors (C, *bshape).  Interior sub-boxes run while the halo
@@ -177,6 +251,11 @@ class ShardedBox:
                 amax = amax.cpu()
             dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)
         self.eng.set_input_range(float(amax.item()))
+        if self.zbricks:
+            self._process_zbrick(brick, Dz, vel_fac, disp, vel)
+            if check_finite:
+                self.eng.check_finite()
+            return disp, vel
         # the engine merges sub-boxes into larger tiles when that is exact (nbe_plan_tiles); split on that grid
         nd = self.eng.plan_tiles(self.bshape, self.nd_local, periodic_box=False)
         interior, boundary = split_interior(nd, self.bshape)

@@ -44,6 +44,8 @@ def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q):
         full = np.random.default_rng(seed_x).standard_normal((3,) + size).astype(np.float32)
         sb = sharding.ShardedBox(eng, size, ndiv, rank, world)
         o, b = sb.origin, sb.bshape
+        want_z = sb.grid[1] == 1 and sb.grid[2] == 1 and b[0] >= 44
+        assert sb.zbricks == want_z, (sb.grid, b, sb.zbricks)
         brick = torch.from_numpy(np.ascontiguousarray(
             full[:, o[0]:o[0] + b[0], o[1]:o[1] + b[1], o[2]:o[2] + b[2]])).cuda()
         disp, vel = torch.zeros_like(brick), torch.zeros_like(brick)
@@ -55,9 +57,11 @@ def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,ndiv", [(2, (128, 64, 64), (2, 1, 1)),
+@pytest.mark.parametrize("world,size,ndiv", [(2, (128, 64, 64), (2, 1, 1)),         # (2,1,1): 64-plane z-slab bricks, level-1 exchange
                                              (4, (128, 128, 64), (4, 2, 1)),        # rank grid (2,2,1): y split, padded
-                                             (4, (256, 64, 64), (4, 1, 1))])        # (4,1,1): bricks periodic in y and x
+                                             (4, (256, 64, 64), (4, 1, 1)),         # (4,1,1): z-slab bricks, level-1 exchange
+                                             (4, (192, 48, 56), (2, 1, 1)),         # 48-plane bricks; the sub-box grid does not divide by 4
+                                             (4, (96, 64, 64), (4, 1, 1))])         # 24-plane bricks: too thin, padded halo recompute
 def test_sharded_equals_single_process(world, size, ndiv):
     import torch.multiprocessing as mp
     import jax_nbody_emulator_with_dj_amd as J
@@ -90,3 +94,7 @@ def test_sharded_equals_single_process(world, size, ndiv):
     # identical arithmetic per voxel (same kernels, same K order): equal to rounding of the tile boundaries
     np.testing.assert_allclose(d_all, d_ref, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(v_all, v_ref, rtol=1e-5, atol=1e-4)
+    grid = J.sharding.rank_grid(world, ndiv, size)
+    if grid[1] == 1 and grid[2] == 1 and size[0] // grid[0] >= 44:
+        # z-slab bricks with the level-1 exchange run the single-GPU schedule of the whole box, cut along z: bit for bit
+        assert np.array_equal(d_all, d_ref) and np.array_equal(v_all, v_ref)

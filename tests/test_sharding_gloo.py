@@ -17,11 +17,15 @@ def test_rank_grid_and_bricks():
     assert S.rank_grid(1, (4, 4, 4)) == (1, 1, 1)
     assert S.rank_grid(2, (4, 4, 4)) == (2, 1, 1)
     assert S.rank_grid(4, (4, 4, 4)) == (4, 1, 1)             # z-only split: the bricks stay periodic in y and x
-    assert S.rank_grid(4, (2, 4, 4)) == (1, 2, 2)             # cubes beat slabs once every axis is padded anyway
-    assert S.rank_grid(8, (4, 4, 4)) == (2, 2, 2)
-    assert S.rank_grid(8, (8, 8, 8)) == (2, 2, 2)
+    assert S.rank_grid(4, (2, 4, 4), zbricks=False) == (1, 2, 2)   # padded bricks: cubes beat slabs once every axis is padded anyway
+    assert S.rank_grid(4, (2, 4, 4)) == (4, 1, 1)             # z-slab bricks need not follow the sub-box grid along z
+    # z-slab bricks that exchange their level-1 context (sharding.py): slabs of >= 44 planes beat cubes
+    assert S.rank_grid(8, (4, 4, 4)) == (8, 1, 1) and S.rank_grid(8, (4, 4, 4), zbricks=False) == (2, 2, 2)
+    assert S.rank_grid(8, (8, 8, 8)) == (8, 1, 1) and S.rank_grid(8, (8, 8, 8), zbricks=False) == (2, 2, 2)
+    assert S.rank_grid(8, (4, 4, 4), (256,) * 3) == (2, 2, 2)          # 32-plane slabs are too thin to hand out 22 planes twice
+    assert S._zbrick_factor(64) < 1.3 < S._halo_factor(256) ** 3
     assert S.rank_grid(16, (4, 4, 4)) == (4, 2, 2)
-    assert S.rank_grid(2, (1, 4, 4)) == (1, 2, 1)
+    assert S.rank_grid(2, (1, 4, 4), zbricks=False) == (1, 2, 1) and S.rank_grid(2, (1, 4, 4)) == (2, 1, 1)
     with pytest.raises(ValueError):
         S.rank_grid(8, (1, 1, 4))
     grid = (2, 2, 2)
@@ -104,3 +108,45 @@ def test_halo_exchange_matches_periodic_gather(world, ndiv, size, pad):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), res
+
+
+def _zface_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grid = (world, 1, 1)
+        coords = S.rank_coords(rank, grid)
+        n = 1000 + 7 * rank                                        # every rank must size its buffers alike: use the max
+        n = 1021
+        s_lo = torch.full((n,), 10 * rank + 1, dtype=torch.uint8)
+        s_hi = torch.full((n,), 10 * rank + 2, dtype=torch.uint8)
+        r_lo, r_hi = torch.zeros(n, dtype=torch.uint8), torch.zeros(n, dtype=torch.uint8)
+        S.exchange_z_faces(s_lo, s_hi, r_lo, r_hi, coords, grid)
+        minus, plus = (rank - 1) % world, (rank + 1) % world
+        # my low halo is the z-minus neighbour's high planes, my high halo the z-plus neighbour's low planes
+        ok = bool((r_lo == 10 * minus + 2).all()) and bool((r_hi == 10 * plus + 1).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_z_face_exchange(world):
+    """The brick mode's one exchange per box: every rank's boundary planes land in the right neighbour's halo, also when
+    both neighbours are the same rank (world 2).  World 1 is a local periodic copy."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zface_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+    a, b = torch.arange(5, dtype=torch.uint8), torch.arange(5, 10, dtype=torch.uint8)
+    ra, rb = torch.zeros(5, dtype=torch.uint8), torch.zeros(5, dtype=torch.uint8)
+    S.exchange_z_faces(a, b, ra, rb, (0, 0, 0), (1, 1, 1))
+    assert torch.equal(ra, b) and torch.equal(rb, a)

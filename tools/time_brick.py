@@ -1,5 +1,12 @@
-"""One rank's share of an N-GPU run of the 512^3 box, timed on one card, for candidate rank grids.  A brick is haloed
-only along the axes its rank grid splits; along the others the region is the periodic box itself (periodic mode)."""
+"""One rank's share of an N-GPU run of the 512^3 box, timed on one card.
+
+  z-slab bricks (rank grid (N,1,1), sharding.py): periodic in y and x, 48 planes of raw-input halo in z, the 22 planes of
+  level-1 context per side exchanged between neighbours (here: copied from the brick's own send buffers -- same bytes,
+  same kernels, no link) -- Engine.brick_encode / brick_finish.
+  padded bricks (the round-1 scheme, NBE_ZBRICKS=0): haloed along the axes the rank grid splits, halo recomputed.
+
+The exchange itself is not part of this timing: 22 planes x 256^2 x 64 channels x 8 B = 738 MB per direction and rank for
+the 512^3 box, whatever N is."""
 import sys, time
 sys.path.insert(0, ".")
 import torch
@@ -10,23 +17,47 @@ e = Engine(device=0)
 e.load_params(StyleNBodyEmulatorVelCore().init(1), False)
 e.set_cosmology(0.3, 0.77)
 N = 512
-cases = [("N=2 (2,1,1)", (2, 1, 1)), ("N=4 (2,2,1)", (2, 2, 1)), ("N=4 (4,1,1)", (4, 1, 1)),
-         ("N=8 (2,2,2)", (2, 2, 2)), ("N=8 (4,2,1)", (4, 2, 1))]
-for name, grid in cases:
+t1 = None
+for n in (1, 2, 4, 8):
+    b = (N // n, N, N)
+    if n == 1:
+        box = torch.randn((3,) + b, device="cuda")
+        for it in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            d, v = e.process_box(box, b, (4, 4, 4), ((48, 48),) * 3, 0.77, 50.0)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        t1 = dt
+        print("N=1 whole box, one periodic tile: %.3f s -> %.1f Mvox/s" % (dt, N ** 3 / dt / 1e6), flush=True)
+        del box, d, v
+        continue
+    H = torch.randn((3, b[0] + 96, N, N), device="cuda")
+    disp = torch.zeros((3,) + b, device="cuda"); vel = torch.zeros_like(disp)
+    nb = e.brick_halo_bytes(b)
+    s_lo, s_hi, r_lo, r_hi = (torch.empty(nb, dtype=torch.uint8, device="cuda") for _ in range(4))
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e.brick_encode(H, b, 0.77, 50.0, s_lo, s_hi)
+        r_hi.copy_(s_lo); r_lo.copy_(s_hi)
+        e.brick_finish(r_lo, r_hi, 0.77, 50.0, disp, vel)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("N=%d z-slab brick %s, level-1 exchange (%.0f MB per direction): %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
+          % (n, b, nb / 1e6, dt, N ** 3 / dt / 1e6, t1 / (n * dt)), flush=True)
+    del H, disp, vel, s_lo, s_hi, r_lo, r_hi
+    torch.cuda.empty_cache()
+# the padded scheme of round 1 for comparison
+for name, grid in (("N=8 (2,2,2)", (2, 2, 2)), ("N=4 (4,1,1)", (4, 1, 1))):
     b = tuple(N // g for g in grid)
     pa = tuple(48 if g > 1 else 0 for g in grid)
     H = torch.randn((3,) + tuple(bb + 2 * p for bb, p in zip(b, pa)), device="cuda")
-    disp = torch.zeros((3,) + b, device="cuda")
-    vel = torch.zeros_like(disp)
+    disp = torch.zeros((3,) + b, device="cuda"); vel = torch.zeros_like(disp)
     nd_local = tuple(4 // g for g in grid)
     nd = e.plan_tiles(b, nd_local, periodic_box=False)
     order = list(range(nd[0] * nd[1] * nd[2]))
     for it in range(2):
-        e.profile_reset(); e.profile_enable(True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         e.process_region(H, pa, b, nd, 0.77, 50.0, disp, vel, order=order)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        e.profile_enable(False)
-        fl = sum(p["flops"] for p in e.profile_read()) / 1e12
-    print("%s: brick %s tiles %s: %.3f s, %.0f TFLOP per rank -> %.1f Mvox/s for the job" % (name, b, nd, dt, fl, N ** 3 / dt / 1e6), flush=True)
+    n = grid[0] * grid[1] * grid[2]
+    print("%s padded brick %s tiles %s: %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
+          % (name, b, nd, dt, N ** 3 / dt / 1e6, t1 / (n * dt)), flush=True)
     del H, disp, vel
