@@ -427,7 +427,7 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
         const int taps = L.kind == 0 ? 27 : L.kind == 2 ? 8 : 1;
         const double gemms = c->vel ? ((has_dx && !g6) ? 3.0 : 2.0) : 1.0;
         c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.cin * taps * gemms;
-        if (cl.skw) c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.fskip->cin * 3.0;   // W_s.x, W_s.dx, dW_s.x
+        if (cl.skw) c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.fskip->cin * ((cl.flags & F_SKIP_NODX) ? 2.0 : 3.0);   // W_s.x, [W_s.dx,] dW_s.x
         c->prof_entries[pe].launches += 1;
         if (c->pending.size() > 4096) prof_collect(c);
     }
@@ -447,7 +447,8 @@ static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer)
 // Periodic-yx mode (x.pad = 1): y and x do not shrink -- every 3x3x3 convolution reads its input's wrap-around halo
 // and writes the interior of a tensor of the same padded size, whose halo is filled afterwards; z shrinks as always.
 // (dst: write the block's result there -- a view with the result's geometry -- instead of allocating it)
-static bool block_fused(nbe_ctx* c, const Layer* L1, bool has_dx) { return c->fuse && has_dx && L1->fskip != nullptr; }
+// (has_dx false: conv_l00, whose skip reads the input field -- fused with F_SKIP_NODX)
+static bool block_fused(nbe_ctx* c, const Layer* L1, bool) { return c->fuse && L1->fskip != nullptr; }
 
 // hidden tensor of a block whose input x has `pad`: interior (Hi - sy) x (Wi - sy).  A fused block gives it the row
 // and plane pitch of x (conv_h3g_kernel fetches the skip's patches of x with the offsets of its own input's).
@@ -486,7 +487,7 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     fill_halo(c, h);
     {
         ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(s);
-        if (fused) { cl.sk = x.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = final_act ? F_ACT : 0; }
+        if (fused) { cl.sk = x.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = (final_act ? F_ACT : 0) | (has_dx ? 0 : F_SKIP_NODX); }
         else { cl.res = inner(s); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
     }
@@ -500,13 +501,16 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
 // Plane indices are in block-input coordinates (result plane j is centred on input plane j + 2): hidden planes
 // [jh, jh + nh) and result planes [js, js + ns) are computed; what precedes them was carried over from the slab
 // before.  h and s have the geometry resblock() would give them (s also serves as the skip / residual, in place).
+// x2: the block input is concat([x, x2]) along the channels (mid channels each, same geometry) without a concat tensor:
+// the gauged f16x3 kernel reads its K chunks from two tensors (fused blocks only)
 static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& h, const Tensor& s,
-                         int js, int ns, int jh, int nh, bool has_dx, bool final_act) {
+                         int js, int ns, int jh, int nh, bool has_dx, bool final_act, const Tensor* x2 = nullptr) {
     const Layer *Ls = find_layer(c, name, "skip"), *L0 = find_layer(c, name, "conv_0"), *L1 = find_layer(c, name, "conv_1");
     if (!Ls || !L0 || !L1) return fail("missing layers of block %s", name);
     const int H = x.p.H, W = x.p.W, pad = x.pad;
     const bool fused = block_fused(c, L1, has_dx);
     if (fused && (h.p.H != H || h.p.W != W)) return fail("internal: hidden tensor of fused block %s lacks the input's pitch", name);
+    if (x2 && (!fused || x2->p.H != H || x2->p.W != W || x2->pad != pad)) return fail("internal: two-source input of block %s", name);
     const Tensor sv = zview(s, js, ns), hv = zview(h, jh, nh);
     const Tensor xs = zview(x, js, ns + 4);                      // what the skip of result planes [js, js + ns) reads
     const int64_t sk_off = (2L * H + (pad ? pad : 2)) * W + (pad ? pad : 2);
@@ -517,12 +521,14 @@ static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Te
     }
     {
         ConvLaunch cl; cl.in = zview(x, jh, nh + 2).p; cl.Dv = nh; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = inner(hv); cl.flags = F_ACT;
+        if (x2) { cl.in2 = zview(*x2, jh, nh + 2).p; cl.csplit_ch = c->mid; }
         if (run_conv(c, *L0, cl, has_dx)) return 1;
     }
     fill_halo(c, hv);
     {
         ConvLaunch cl; cl.in = zview(h, js, ns + 2).p; cl.Dv = ns; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(sv);
-        if (fused) { cl.sk = xs.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = final_act ? F_ACT : 0; }
+        if (fused) { cl.sk = xs.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = (final_act ? F_ACT : 0) | (has_dx ? 0 : F_SKIP_NODX);
+                     if (x2) { cl.sk2 = zview(*x2, js, ns + 4).p; cl.sk_split_ch = c->mid; } }
         else { cl.res = inner(sv); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
     }
@@ -549,7 +555,8 @@ static int downblock(nbe_ctx* c, const char* name, const Tensor& x, Tensor* out)
 
 // up-sample into planes [mid/4, 2*mid/4) of the concat tensor (core :166-169: concat([skip, up]))
 // (xcrop: centre crop of x in y and x before up-sampling; the result goes to the interior of cat)
-static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& cat, int xcrop = 0) {
+// (g0 < 0: into the second half of a 2 * mid channel concat tensor; g0 = 0: into a mid channel tensor of its own)
+static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& cat, int xcrop = 0, int g0 = -1) {
     const Layer* L = find_layer(c, name, "conv_0");
     if (!L) return fail("missing layer %s/conv_0", name);
     xcrop += x.pad;                                              // a periodic halo of x is not up-sampled either
@@ -562,7 +569,7 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
     for (int p = 0; p < (up8 ? 1 : 8); ++p) {
         ConvLaunch cl; cl.in = x.p; cl.in_off = ((int64_t)xcrop * x.p.W + xcrop);
         cl.Dv = x.p.D; cl.Hv = Hx; cl.Wv = Wx; cl.out = inner(cat);
-        cl.out_g0 = c->mid / (c->prec == PREC_F16 ? 8 : 4); cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
+        cl.out_g0 = g0 >= 0 ? g0 : c->mid / (c->prec == PREC_F16 ? 8 : 4); cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
         cl.flags = F_ACT; cl.set = up8 ? -1 : p;
         if (run_conv(c, *L, cl, true)) return 1;
     }
@@ -844,7 +851,9 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
     // planes of h0 / a / h1: those are carried over from the slab before (a copy of a few planes) instead of being
     // recomputed, so every layer computes every plane exactly once.
     const int sy = pad ? 0 : 2;
-    Tensor h0 = tallocp(c, m, S + 6, Hi - sy, Wi - sy, pad), a = tallocp(c, m, S + 4, Hi - 2 * sy, Wi - 2 * sy, pad);
+    const Layer* L00 = find_layer(c, "conv_l00", "conv_1");
+    if (!L00) return fail("missing layer conv_l00/conv_1");
+    Tensor h0 = alloc_hidden(c, m, S + 6, tin, block_fused(c, L00, false)), a = tallocp(c, m, S + 4, Hi - 2 * sy, Wi - 2 * sy, pad);
     const Layer *L01 = find_layer(c, "conv_l01", "conv_1"), *Lr00 = find_layer(c, "conv_r00", "conv_1"), *Lr01 = find_layer(c, "conv_r01", "conv_1");
     if (!L01 || !Lr00 || !Lr01) return fail("missing conv_1 layers of the level-0 blocks");
     Tensor h1 = alloc_hidden(c, m, S + 2, a, block_fused(c, L01, true));
@@ -970,7 +979,11 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
     // Persistent slab tensors of the level-0 decoder, with the same carry-over of the overlaps (8 / 6 / 4 / 2 planes of
     // the concat tensor, the hidden and the result of conv_r00, the hidden of conv_r01).
     const int Hs = skip0.p.H - 2 * pad, Ws = skip0.p.W - 2 * pad;
-    Tensor cat = tallocp(c, 2 * m, S + 8, Hs, Ws, pad), hq = alloc_hidden(c, 2 * m, S + 6, cat, block_fused(c, Lr00, true));
+    // Fused blocks on the gauged f16x3 kernel read concat([skip, up]) from two tensors (core :168-169 without the concat):
+    // the slab's planes of the skip connection where they are, the up-sampled half in a mid-channel tensor of its own.
+    static const bool two_off = getenv("NBE_TWOSRC") && atoi(getenv("NBE_TWOSRC")) == 0;           // A/B switch
+    const bool two = block_fused(c, Lr00, true) && !two_off && c->mid % 16 == 0;   // the kernel switches sources between 16-channel chunks
+    Tensor cat = tallocp(c, two ? m : 2 * m, S + 8, Hs, Ws, pad), hq = alloc_hidden(c, 2 * m, S + 6, cat, block_fused(c, Lr00, true));
     Tensor q = tallocp(c, m, S + 4, Hs - 2 * sy, Ws - 2 * sy, pad), hy = alloc_hidden(c, m, S + 2, q, block_fused(c, Lr01, true));
     Tensor y = tallocp(c, c->out_chan, S, Hs - 4 * sy, Ws - 4 * sy, pad);
     if (cat.off < 0 || hq.off < 0 || q.off < 0 || hy.off < 0 || y.off < 0) return fail("workspace exhausted (level-0 decoder slabs)");
@@ -978,14 +991,17 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
         const int n = std::min(S, Yo - z);
         const bool first = z == 0;
         const int c0 = first ? 0 : 8, cn = first ? n + 8 : n;     // new planes of the concat tensor: [c0, c0 + cn)
-        if (!c->dry) launch_crop(zview(skip0, z + c0, cn).p, 0, zview(cat, c0, cn).p, 0, c->vel, c->stream, 0);
-        if (upblock(c, "up_r0", zview(r, (z + c0) / 2, cn / 2), zview(cat, c0, cn), rcrop)) return 1;
+        if (!two && !c->dry) launch_crop(zview(skip0, z + c0, cn).p, 0, zview(cat, c0, cn).p, 0, c->vel, c->stream, 0);
+        if (upblock(c, "up_r0", zview(r, (z + c0) / 2, cn / 2), zview(cat, c0, cn), rcrop, two ? 0 : -1)) return 1;
         fill_halo(c, zview(cat, c0, cn));
+        // two sources: slab-local plane j of the concat is plane z + j of the skip connection
+        const Tensor sk = two ? zview(skip0, z, std::min(S + 8, skip0.p.D - z)) : cat;
+        const Tensor* up2 = two ? &cat : nullptr;
         if (first) {
-            if (resblock_part(c, "conv_r00", cat, hq, q, 0, n + 4, 0, n + 6, true, true)) return 1;
+            if (resblock_part(c, "conv_r00", sk, hq, q, 0, n + 4, 0, n + 6, true, true, up2)) return 1;
             if (resblock_part(c, "conv_r01", q, hy, y, 0, n, 0, n + 2, true, false)) return 1;
         } else {
-            if (resblock_part(c, "conv_r00", cat, hq, q, 4, n, 6, n, true, true)) return 1;
+            if (resblock_part(c, "conv_r00", sk, hq, q, 4, n, 6, n, true, true, up2)) return 1;
             if (resblock_part(c, "conv_r01", q, hy, y, 0, n, 2, n, true, false)) return 1;
         }
         if (z + S < Yo) {
@@ -1242,7 +1258,7 @@ static int wire_gauge(nbe_ctx* c) {
         // the skip can run inside conv_1 (conv_h3g_kernel<false>): f16x3, the block input has a tangent, the wide tile,
         // and the groups of both fit the kernel's table
         static const bool no_fuse = getenv("NBE_FUSE") && atoi(getenv("NBE_FUSE")) == 0;        // A/B switch
-        if (c->prec == PREC_F16X3 && !no_fuse && strcmp(b, "conv_l00") && !L1->pwn.w &&
+        if (c->prec == PREC_F16X3 && !no_fuse && !L1->pwn.w &&
             3 * (L1->pw.cin_pad / 16) + Ls->pw.cin_pad / 16 <= NBE_MAX_GROUPS) {
             L1->fskip = Ls; Ls->b_sub = L1->beta;
             const int nb = L1->pw.ctiles * 32 * L1->pw.ni;
@@ -1334,7 +1350,8 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
         const std::string key = std::string(b) + "/" + l;
         const nbe_layer_desc& d = *by_name[key];
         Layer& L = c->layers[key];
-        const std::vector<double>& a = al[std::string(reader) + "/conv_0"];
+        static const std::vector<double> none(4096, 0.0);          // reader == nullptr: the input carries no gauge (conv_l00)
+        const std::vector<double>& a = reader ? al[std::string(reader) + "/conv_0"] : none;
         // a skip that runs inside its block's conv_1 (Layer::b_sub): the kernel's epilogue adds beta_1[o] * (W_s.x) as well
         const std::vector<double>* bsub = L.b_sub ? &be[std::string(b) + "/conv_1"] : nullptr;
         const int k3 = d.k * d.k * d.k;
@@ -1351,7 +1368,8 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
         return 0;
     };
     for (const char* b : kBlocks) {
-        if (!strncmp(b, "down_", 5) || !strncmp(b, "up_", 3) || !strcmp(b, "conv_l00")) continue;
+        if (!strncmp(b, "down_", 5) || !strncmp(b, "up_", 3)) continue;
+        if (!strcmp(b, "conv_l00")) { if (c->layers[std::string(b) + "/skip"].b_sub && fold(b, "skip", nullptr, 0)) return 1; continue; }
         if (fold(b, "skip", b, 0)) return 1;
     }
     if (fold("down_l0", "conv_0", "conv_r00", 0) || fold("down_l1", "conv_0", "conv_r1", 0) ||

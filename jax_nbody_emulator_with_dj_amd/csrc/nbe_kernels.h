@@ -39,7 +39,7 @@ constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
 constexpr int NBE_MAX_GROUPS = 64;
 
 enum ConvMode { MODE_FLAT3 = 0, MODE_FLAT1 = 1, MODE_DOWN = 2 };
-enum ConvFlags { F_ACT = 1, F_RES = 2 };
+enum ConvFlags { F_ACT = 1, F_RES = 2, F_SKIP_NODX = 4 };   // F_SKIP_NODX: the fused skip's input has no tangent (conv_l00)
 
 // Tile constants shared by the weight packer and the conv kernel.
 constexpr int TILE_VOX = 256;                 // voxels per workgroup tile

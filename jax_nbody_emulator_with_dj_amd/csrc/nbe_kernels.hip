@@ -259,6 +259,7 @@ int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, h
     // second input segment and fused skip (conv_h3g_kernel<false>; every other kernel ignores them, and the launcher
     // refuses them where they would be ignored)
     ka.x2 = L.in2.x; ka.dx2 = L.in2.dx; ka.in2_pstride = L.in2.pstride;
+    if (L.csplit_ch % 16 != 0 || L.sk_split_ch % 16 != 0) return 1;          // sources switch between 16-channel chunks
     ka.csplit = L.csplit_ch > 0 ? L.csplit_ch / 16 : (1 << 30);
     ka.xs = ka.dxs = ka.xs2 = ka.dxs2 = nullptr; ka.s_pstride = ka.s2_pstride = 0; ka.s_csplit = 1 << 30;
     ka.ws = ka.dws = nullptr; ka.nskip = 0; ka.dws_delta = 0;
@@ -266,7 +267,7 @@ int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, h
         if (L.sk.H != L.in.H || L.sk.W != L.in.W) return 1;                   // the fused skip shares the input's pitch
         // patch origin of output tile (z, y0, x0) = the skip's voxel minus one row and one column (centre tap)
         const int64_t o = (L.sk_off - L.sk.W - 1) * 4;                        // floats: one voxel of a plane is 16 bytes
-        ka.xs = L.sk.x + o; ka.dxs = L.sk.dx + o; ka.s_pstride = L.sk.pstride;
+        ka.xs = L.sk.x + o; ka.dxs = (L.flags & F_SKIP_NODX) ? ka.xs : L.sk.dx + o; ka.s_pstride = L.sk.pstride;
         if (L.sk_split_ch > 0) { ka.xs2 = L.sk2.x + o; ka.dxs2 = L.sk2.dx + o; ka.s2_pstride = L.sk2.pstride; ka.s_csplit = L.sk_split_ch / 16; }
         ka.ws = L.skw->w; ka.dws = L.skw->dw; ka.nskip = L.skw->cin_pad / 16;
     }

@@ -1394,8 +1394,13 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
             }
             NBE_SB; MM8(yc, a1w, b1x, 0, nb, px); NBE_SB;                    // W_s.x, correction terms
             MM8(ym, a0, b1x, 2, nb, px); NBE_SB;                             //        main term
-            MM8(dc, a1w, b1d, 4, nb, px); NBE_SB;                            // W_s.dx~
-            MM8(dm, a0, b1d, 6, nb, px); NBE_SB;
+            if (!(a.flags & F_SKIP_NODX)) {                                  // (conv_l00: the input field has no tangent)
+                MM8(dc, a1w, b1d, 4, nb, px); NBE_SB;                        // W_s.dx~
+                MM8(dm, a0, b1d, 6, nb, px); NBE_SB;
+            } else if (px) {
+#pragma unroll
+                for (int k = 4; k < 8; ++k) dma_slot(k, nb);
+            }
             MM8(dc, a1d, b1x, 8, nb, px); NBE_SB;                            // dW_s~.x
             MM8(dm, a0d, b1x, 10, nb, px); NBE_SB;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");

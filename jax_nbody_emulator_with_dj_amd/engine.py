@@ -300,12 +300,24 @@ class Engine:
     def brick_encode(self, haloed, bshape, Dz, vel_fac, send_lo, send_hi):
         """haloed: CUDA tensor (C, b0 + 96, S1, S2); send_lo / send_hi: CUDA uint8 tensors of brick_halo_bytes()."""
         self._follow_torch_stream(haloed)
+        b = tuple(int(v) for v in bshape)
+        # the kernels read exactly this much: check before anything is launched
+        if tuple(haloed.shape) != (self.in_chan, b[0] + 96, b[1], b[2]) or haloed.dtype != torch.float32 or not haloed.is_contiguous():
+            raise NBEError("haloed brick must be a contiguous float32 (C, b0 + 96, S1, S2) = %s tensor; got %s %s"
+                           % ((self.in_chan, b[0] + 96, b[1], b[2]), tuple(haloed.shape), haloed.dtype))
+        n = self.brick_halo_bytes(b)
+        for t in (send_lo, send_hi):
+            if t.numel() * t.element_size() < n or not t.is_cuda:
+                raise NBEError("brick exchange buffers must be CUDA tensors of at least %d bytes" % n)
         check(self._l.nbe_brick_encode(self._h, _ptr(haloed), (C.c_int64 * 3)(*[int(v) for v in bshape]), float(Dz),
                                        float(vel_fac), _ptr(send_lo), _ptr(send_hi)))
 
     def brick_finish(self, recv_lo, recv_hi, Dz, vel_fac, disp, vel):
         self._follow_torch_stream(disp)
         half = disp.element_size() == 2
+        for t in (recv_lo, recv_hi):
+            if not t.is_cuda:
+                raise NBEError("brick exchange buffers must be CUDA tensors")
         check(self._l.nbe_brick_finish(self._h, _ptr(recv_lo), _ptr(recv_hi), float(Dz), float(vel_fac), _ptr(disp),
                                        _ptr(vel), 1 if half else 0))
 

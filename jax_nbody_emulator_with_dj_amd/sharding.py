@@ -221,7 +221,7 @@ class ShardedBox:
         self.grid = rank_grid(world_size, ndiv, self.size, zbricks=zbricks and exact)
         self.coords = rank_coords(rank, self.grid)
         self.origin, self.bshape = brick_extent(self.coords, self.grid, size)
-        self.zbricks = (zbricks and exact and self.grid[1] == 1 and self.grid[2] == 1 and self.bshape[0] % 8 == 0
+        self.zbricks = (zbricks and exact and self.grid[0] > 1 and self.grid[1] == 1 and self.grid[2] == 1 and self.bshape[0] % 8 == 0
                         and self.bshape[0] >= BRICK_MIN_DEPTH and self.bshape[1] >= 48 and self.bshape[2] >= 48)
         self.nd_local = tuple(max(1, n // g) for n, g in zip(ndiv, self.grid))
         self.group = group

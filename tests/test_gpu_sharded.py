@@ -45,7 +45,7 @@ def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q, zb=True):
         full = np.random.default_rng(seed_x).standard_normal((3,) + size).astype(np.float32)
         sb = sharding.ShardedBox(eng, size, ndiv, rank, world)
         o, b = sb.origin, sb.bshape
-        want_z = zb and sb.grid[1] == 1 and sb.grid[2] == 1 and b[0] >= 44
+        want_z = zb and sb.grid[0] > 1 and sb.grid[1] == 1 and sb.grid[2] == 1 and b[0] >= 44
         assert sb.zbricks == want_z, (sb.grid, b, sb.zbricks)
         brick = torch.from_numpy(np.ascontiguousarray(
             full[:, o[0]:o[0] + b[0], o[1]:o[1] + b[1], o[2]:o[2] + b[2]])).cuda()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 2: two-source concat + first-block skip fusion: model / api / range / sharded tests, bench A/B
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_api.py tests/test_gpu_sharded.py tests/test_gpu_model.py tests/test_gpu_range.py tests/test_gpu_edge_cases.py -x -q -m gpu > gpurun_out/r02_sixth_tests.log 2>&1
+rc=$?; tail -4 gpurun_out/r02_sixth_tests.log
+[ $rc -ne 0 ] && exit $rc
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict --no-host-path > gpurun_out/r02_bench_two.json 2> gpurun_out/r02_bench_two.err && \
+NBE_TWOSRC=0 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict --no-host-path > gpurun_out/r02_bench_notwo.json 2> gpurun_out/r02_bench_notwo.err
+rc=$?
+for f in two notwo; do python - <<PY
+import json
+try:
+    d=json.loads([l for l in open("gpurun_out/r02_bench_$f.json") if l.startswith("{")][-1])
+    print("$f", round(d["value"]/1e6,2), "Mvox/s", round(d["ms_per_step"],1), "ms", d["roofline"]["kernel"], round(d["roofline"]["frac"],4))
+    for k in d["kernels"][:9]: print("   ", k)
+except Exception as e: print("$f", e)
+PY
+done
+exit $rc
