@@ -394,6 +394,9 @@ static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 =
     return b;
 }
 
+static bool narrow_off() { static const bool v = getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0; return v; }   // A/B switch
+static bool narrow_tile(const Layer* L) { return L->pwn.w && !narrow_off(); }
+
 // launch one convolution layer (or record it in a dry run)
 static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool has_dx) {
     if (c->dry) return 0;
@@ -407,8 +410,7 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
         if (!(g6 && c->fuse && L.fskip)) return fail("internal error: fused skip requested for %s/%s", L.block.c_str(), L.layer.c_str());
         cl.bias = L.bias_f;
     }
-    static const bool no_narrow = getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0;      // A/B switch
-    const PackedW& pw = (g6 && L.pwn.w && !no_narrow) ? L.pwn : L.pw;
+    const PackedW& pw = (g6 && L.kind == 0 && narrow_tile(&L)) ? L.pwn : L.pw;
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
         pe = prof_entry(c, conv_name(pw, c->vel, has_dx, g6, cl.set < 0));
@@ -487,7 +489,7 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     fill_halo(c, h);
     {
         ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(s);
-        if (fused) { cl.sk = x.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = (final_act ? F_ACT : 0) | (has_dx ? 0 : F_SKIP_NODX); }
+        if (fused) { cl.sk = x.p; cl.sk_off = sk_off; cl.skw = narrow_tile(L1) ? &Ls->pwn : &Ls->pw; cl.flags = (final_act ? F_ACT : 0) | (has_dx ? 0 : F_SKIP_NODX); }
         else { cl.res = inner(s); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
     }
@@ -527,7 +529,7 @@ static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Te
     fill_halo(c, hv);
     {
         ConvLaunch cl; cl.in = zview(h, js, ns + 2).p; cl.Dv = ns; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(sv);
-        if (fused) { cl.sk = xs.p; cl.sk_off = sk_off; cl.skw = &Ls->pw; cl.flags = (final_act ? F_ACT : 0) | (has_dx ? 0 : F_SKIP_NODX);
+        if (fused) { cl.sk = xs.p; cl.sk_off = sk_off; cl.skw = narrow_tile(L1) ? &Ls->pwn : &Ls->pw; cl.flags = (final_act ? F_ACT : 0) | (has_dx ? 0 : F_SKIP_NODX);
                      if (x2) { cl.sk2 = zview(*x2, js, ns + 4).p; cl.sk_split_ch = c->mid; } }
         else { cl.res = inner(sv); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
@@ -1183,7 +1185,7 @@ static void free_layers(nbe_ctx* c) {
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
-        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pwn.w); (void)hipFree(L.bias_f);
+        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pwn.w); (void)hipFree(L.pwn.dw); (void)hipFree(L.bias_f);
         (void)hipFree(L.alpha); (void)hipFree(L.beta);
     }
     c->layers.clear();
@@ -1258,7 +1260,7 @@ static int wire_gauge(nbe_ctx* c) {
         // the skip can run inside conv_1 (conv_h3g_kernel<false>): f16x3, the block input has a tangent, the wide tile,
         // and the groups of both fit the kernel's table
         static const bool no_fuse = getenv("NBE_FUSE") && atoi(getenv("NBE_FUSE")) == 0;        // A/B switch
-        if (c->prec == PREC_F16X3 && !no_fuse && !L1->pwn.w &&
+        if (c->prec == PREC_F16X3 && !no_fuse && (!L1->pwn.w || Ls->pwn.dw) &&
             3 * (L1->pw.cin_pad / 16) + Ls->pw.cin_pad / 16 <= NBE_MAX_GROUPS) {
             L1->fskip = Ls; Ls->b_sub = L1->beta;
             const int nb = L1->pw.ctiles * 32 * L1->pw.ni;
@@ -1365,6 +1367,7 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
                 }
         HIPCHK(hipMemcpy(L.dwn, eff.data(), eff.size() * 4, hipMemcpyHostToDevice));
         launch_pack(L.dwn, d.cout, d.cin, L.kind, L.pw, L.pw.dw, c->stream);
+        if (L.pwn.dw) launch_pack(L.dwn, d.cout, d.cin, L.kind, L.pwn, L.pwn.dw, c->stream);
         return 0;
     };
     for (const char* b : kBlocks) {
@@ -1413,12 +1416,13 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
         HIPCHK(hipMemcpy(pw.bias, d.bias, d.cout * 4, hipMemcpyHostToDevice));
         // (cout <= 4: the head convolution 64 -> 3.  Narrow test models, cout 8 or 16, stay on the wide tile so that they
         // exercise what production-width layers run, skip fusion included.)
-        if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && d.cout <= 4 && !L.first) {
+        if (c->prec == PREC_F16X3 && c->vel && (L.kind == 0 || L.kind == 1) && d.cout <= 4 && !L.first) {
             PackedW& pn = L.pwn;                               // same layer, 16-cout tiles (conv_h3g_kernel<true>)
             pn = pw; pn.w = nullptr; pn.dw = nullptr;
             pn.cout_t = 16; pn.ctiles = 1;
             pn.floats = (int64_t)16 * mode_nseg(pn.mode) * mode_taps(pn.mode) * pn.cin_pad;
             HIPCHK(hipMalloc((void**)&pn.w, pn.floats * 4));
+            if (L.kind == 1) HIPCHK(hipMalloc((void**)&pn.dw, pn.floats * 4));   // a skip that runs inside the narrow conv_1
         }
         HIPCHK(hipMalloc((void**)&L.bias0, nb * 4));
         HIPCHK(hipMemcpy(L.bias0, pw.bias, nb * 4, hipMemcpyDeviceToDevice));
@@ -1441,6 +1445,7 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             launch_pack(L.wn, d.cout, d.cin, L.kind, pw, pw.w, c->stream);
             if (c->vel) launch_pack(L.dwn, d.cout, d.cin, L.kind, pw, pw.dw, c->stream);
             if (L.pwn.w) launch_pack(L.wn, d.cout, d.cin, L.kind, L.pwn, L.pwn.w, c->stream);
+            if (L.pwn.dw) launch_pack(L.dwn, d.cout, d.cin, L.kind, L.pwn, L.pwn.dw, c->stream);
         }
         c->layers[L.block + "/" + L.layer] = L;
     }
@@ -1581,6 +1586,7 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
                         use_gauge ? L.b_sub : nullptr);
         launch_pack(L.wn, L.cout, L.cin, L.kind, L.pw, L.pw.w, c->stream);
         if (L.pwn.w) launch_pack(L.wn, L.cout, L.cin, L.kind, L.pwn, L.pwn.w, c->stream);
+        if (L.pwn.dw) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pwn, L.pwn.dw, c->stream);
         if (c->vel && !(use_gauge && L.g6)) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pw, L.pw.dw, c->stream);
     }
     c->gauge_active = use_gauge;

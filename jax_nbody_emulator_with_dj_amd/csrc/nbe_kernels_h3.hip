@@ -82,6 +82,8 @@ __device__ __forceinline__ void h3_store2(const ConvKArgs& a, int ct, int it, in
             }
         }
     }
+    // (16-byte stores through v_permlane32_swap pairs -- guide T21 -- were measured on the first layer, the up-sampling and
+    // the stride-2 launches, which are write-bound: no change; the 8-byte form below keeps 24 registers fewer alive.)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int jt = p >> 2, k = p & 3;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     };
     zero_acc();
     // this lane's two input positions -> (z, y, x) once; the output voxel of parity p follows by shifts
-    int pz[2], py[2], px[2];
+    int ob2[2];                                      // output voxel of parity 0 (< 2^31: tiles are <= 608^3 voxels)
     bool ok[2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
         const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
         const int yy = rem / a.W, xx = rem - yy * a.W;
         ok[jt] = q < a.Q && xx < a.Wv && yy < a.Hv && z < a.Dv;
-        pz[jt] = z; py[jt] = yy; px[jt] = xx;
+        ob2[jt] = ok[jt] ? (2 * z * a.Ho + 2 * yy) * a.Wo + 2 * xx : 0;
     }
 
     for (int st = 0; st < nstage; ++st) {
@@ -472,14 +474,9 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dxh, dc[jt], 0, 0, 0);
         }
         if (c == nchunk - 1) {                               // parity p is complete: store it, start the next
-            long o[2];
-            bool okk[2];
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                okk[jt] = ok[jt];
-                o[jt] = okk[jt] ? ((long)(2 * pz[jt] + ((p >> 2) & 1)) * a.Ho + (2 * py[jt] + ((p >> 1) & 1))) * a.Wo + (2 * px[jt] + (p & 1)) : 0;
-            }
-            h3_store2<true, true>(a, ct, it, lh, o, okk, ym, yc, dm, dc);
+            const int po = (((p >> 2) & 1) * a.Ho + ((p >> 1) & 1)) * a.Wo + (p & 1);      // this parity's shift (uniform)
+            const long o[2] = {(long)ob2[0] + (ok[0] ? po : 0), (long)ob2[1] + (ok[1] ? po : 0)};
+            h3_store2<true, true>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
             zero_acc();
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W(st + 1) has landed (stores included: they are few)
@@ -1217,24 +1214,25 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     // Groups [ngroups, ngroups + nskip) are the block's 1x1x1 skip (style_blocks_vel.py:108-123) fused into this,
     // the block's last, convolution: one 16-channel chunk of the BLOCK INPUT each (its patch placed so that the centre
     // tap is the skip's voxel), weights [W_s | dW_s~] of that chunk -- see the skip body below.
-    const int nskip = NARROW ? 0 : a.nskip;
+    const int nskip = a.nskip;
     // Per group the host has prepared {x, dx, w, plane stride} (ConvKArgs::gs, in the kernel-argument segment): all that
     // depends on the group but not on the tile.  The tile adds its patch origin and its cout tile.  (Computing the
     // sources here from the dozen pointers and strides they derive from kept ~80 more SGPRs alive through the loop.)
     // (the skip's input has the row and plane pitch of the layer's input -- the engine allocates the block's hidden
     // tensor with the pitch of the block input -- so one patch origin and one set of per-lane offsets serve both)
     const long to = (((long)z * a.H + y0) * a.W + x0) * 16;
-    const long wcm = (long)ct * ngroups * WGU * 16, wcs = (long)ct * nskip * 256 * 16;
+    const long wcm = (long)ct * ngroups * WGU * 16, wcs = (long)ct * nskip * TAPU * 16;   // a skip chunk: one "tap" of W_s (and of dW_s~)
     struct Nxt { const char *x, *dx, *w0; long psb; bool sk; } nx;   // sources of the group being fetched
     auto set_next = [&](int g) {
         const ConvGroupSrc e = a.gs[g];
-        const bool sk = !NARROW && g >= ngroups;
+        const bool sk = g >= ngroups;
         nx.x = e.x + to; nx.dx = e.dx + to; nx.psb = e.psb; nx.w0 = e.w + (sk ? wcs : wcm); nx.sk = sk;
     };
     auto dma_w = [&](int buf, int t) {
         const int n = wave + 8 * t;
+        constexpr int PER = TAPU / 64;                           // wave-instructions per skip weight set: 4 / 1
         if (!nx.sk) { if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, lane16, lds + buf * WGU + n * 64); }
-        else if (n < 8) dma16s(nx.w0 + (n < 4 ? 0 : a.dws_delta) + (long)(n & 3) * 1024, lane16, lds + buf * WGU + n * 64);
+        else if (n < 2 * PER) dma16s(nx.w0 + (n < PER ? 0 : a.dws_delta) + (long)(n % PER) * 1024, lane16, lds + buf * WGU + n * 64);
     };
     unsigned xoff[3];                                            // per-lane byte offset inside a patch plane
     bool xval[3];
@@ -1376,7 +1374,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     //     dW_s - W_s (.) a[i] - beta[o] W_s
     // (launch_modulate a_in / b_sub): y += W_s.x,  dy += W_s.dx~ + dW_s~.x -- six products on the centre tap, parts
     // paired in K as for tap 4 above: [wh|wl].[xl|xh] -> correction, [0|wh].[xl|xh] -> main.
-    if (!NARROW) {
+    {
         for (int sc = 0; sc < nskip; ++sc) {
             const int g = ngroups + sc;
             const bool px = sc + 1 < nskip;
@@ -1509,7 +1507,7 @@ static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
     ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     ka.ntiles = ka.Dv * ka.tny * ka.tnx;
     if (ctiles != (ka.cout_groups + G::CT / 8 - 1) / (G::CT / 8)) return 1;
-    const int ngroups = 3 * ka.nchunk, nskip = NARROW ? 0 : ka.nskip;
+    const int ngroups = 3 * ka.nchunk, nskip = ka.nskip;
     if (ngroups + nskip > NBE_MAX_GROUPS) return 1;              // the engine does not wire such a network for this kernel
     for (int g = 0; g < ngroups; ++g) {
         const int chunk = g / 3, dz = g - chunk * 3;
@@ -1524,7 +1522,7 @@ static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
         const long ps = second ? ka.s2_pstride : ka.s_pstride;
         const long off = (long)(second ? sc - ka.s_csplit : sc) * 4 * ps * 16;
         ka.gs[ngroups + sc] = {(const char*)(second ? ka.xs2 : ka.xs) + off, (const char*)(second ? ka.dxs2 : ka.dxs) + off,
-                               (const char*)ka.ws + (long)sc * 256 * 16, ps * 16};
+                               (const char*)ka.ws + (long)sc * G::TAPU * 16, ps * 16};
     }
     ka.dws_delta = nskip ? (const char*)ka.dws - (const char*)ka.ws : 0;
     dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
@@ -1888,7 +1886,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
     const bool split = pw.prec == PREC_F16X3;
     // a second input segment / a fused skip exist only in the wide gauged f16x3 kernel
-    if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split && pw.cout_t != 16)) return 1;
+    if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split)) return 1;
 #define NBE_VD(F, ...)                                                          \
     if (vel) { if (has_dx) F<__VA_ARGS__, true, true>(ka, ct, s); else F<__VA_ARGS__, true, false>(ka, ct, s); } \
     else F<__VA_ARGS__, false, false>(ka, ct, s);
