@@ -1896,7 +1896,14 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         if (split) return pw.cout_t == 16 ? launch_h3g<true>(ka, ct, s) : launch_h3g<false>(ka, ct, s);
         return launch_h2q<false, true>(ka, ct, s);
     }
-    if (pw.mode == MODE_FLAT3 && !flat3 && ka.in_off == 0 && ka.osz == 1) {
+    // A/B switch (NBE_L0_FLAT=1): the first layer (no input tangent, Cin = 3 padded to 16; 64 channels x (hi, lo) x (y, dy)
+    // out for 3 channels in) on the flat tiling, which stores 4 KB runs per plane where the 8 x 32 patch tiling stores
+    // 512-byte row pieces.  Measured: 49.1 vs 47.6 ms per box -- the layer is not limited by the shape of its stores
+    // (nor by their width: 16-byte stores through v_permlane32_swap changed nothing either); its matrix pipe is 43 % busy
+    // on a K padded from 81 to 432.
+    static const bool l0_flat = getenv("NBE_L0_FLAT") && atoi(getenv("NBE_L0_FLAT")) == 1;
+    const bool first_flat = l0_flat && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.nchunk == 1;
+    if (pw.mode == MODE_FLAT3 && !flat3 && !first_flat && ka.in_off == 0 && ka.osz == 1) {
         if (split && vel && has_dx && !shape32 && sched == 0) return launch_h3q(ka, ct, s);
         if (split && !vel && !shape32) return launch_h2q<true>(ka, ct, s);
         if (!split && vel && has_dx && !shape32) return launch_h2q<false>(ka, ct, s);
