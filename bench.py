@@ -72,6 +72,9 @@ def main():
                          "f32: strict float32 MFMA")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 reference pass")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-array (NumPy in / NumPy out) pass")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="no per-kernel HIP events in the timed region (no roofline object): the tiles then replay from "
+                         "captured hipGraphs, which profiling turns off -- for the graph A/B (NBE_GRAPH=0 / 1)")
     args = ap.parse_args()
 
     import torch
@@ -129,6 +132,7 @@ def main():
         torch.cuda.synchronize()
 
     phases = {}
+    graph_info = {}
 
     def measure(precision, warmup, steps):
         """W untimed + K timed passes of the whole box with one arithmetic mode."""
@@ -151,14 +155,15 @@ def main():
         fence()
         eng.debug_phase_cycles()                  # timing-probe builds: reset the in-kernel phase counters
         eng.profile_reset()
-        eng.profile_enable(True)
+        eng.profile_enable(not args.no_profile)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         fence()
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
-        prof = eng.profile_read()
+        prof = [] if args.no_profile else eng.profile_read()
+        replays = eng.query("graph_replays")
         ph = eng.debug_phase_cycles()
         if ph[8] > 0:                             # NBE_BUILD_DBG=1 only: where the dominant kernel's wave cycles go
             tot = sum(ph[:8])
@@ -172,6 +177,7 @@ def main():
             dt = float(t.item())
         ok = bool(torch.isfinite(disp).all().item()) and (velo is None or bool(torch.isfinite(velo).all().item()))
         eng.close()
+        graph_info["replays"] = replays
         return dt, prof, ok, plan
 
     def traffic_key(precision, plan):
@@ -208,6 +214,7 @@ def main():
                 "launches": dom["launches"], "share_of_kernel_time": dom["ms"] / tot_ms if tot_ms else None}
 
     dt, prof, ok, plan = measure(args.precision, args.warmup, args.steps)
+    main_replays = graph_info.get("replays")
 
     def measure_host_path(steps):
         """The reference's call shape (subbox.py:139-219): host NumPy array in, host NumPy arrays out, through the public
@@ -260,7 +267,8 @@ def main():
                                    "synthetic seeded weights, box resident in HBM" % (N, *ndiv, vel, "Vel" if vel else ""),
                        "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,),
                        "internal_tiles": plan, "precision": args.precision,
-                       "traffic_key": traffic_key(args.precision, plan)},
+                       "traffic_key": traffic_key(args.precision, plan),
+                       "tiles_replayed_from_hipgraphs": main_replays},
             "finite": ok,
         }
         if prof:
