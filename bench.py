@@ -14,9 +14,10 @@ the output boxes resident in HBM.  Arithmetic: float32-equivalent f16x3 split MF
 strict float32 MFMA path is timed on the same box and reported under "strict_f32".  Weights are synthetic (seeded; the pretrained blob is not
 available), which changes neither the FLOPs nor the bytes.  Rank 0 prints ONE JSON line.
 
-N > 1: the sub-box grid is sharded as bricks over the ranks (jax_nbody_emulator_with_dj_amd/sharding.py);
-each rank exchanges its 48-voxel halo with its neighbours over RCCL P2P every step and processes its own
-sub-boxes; total work is fixed (strong scaling).
+N > 1: the box is sharded as bricks over the ranks (jax_nbody_emulator_with_dj_amd/sharding.py) -- z-slabs whenever a
+slab is at least 44 planes deep: per step each rank exchanges 48 planes of raw input and 22 planes of down_l0 output
+with its two z neighbours over RCCL P2P and otherwise works alone (no halo recompute below the full-resolution level);
+total work is fixed (strong scaling).
 """
 
 import argparse
@@ -147,7 +148,10 @@ def main():
         else:
             sb = sharding.ShardedBox(eng, size, ndiv, rank, world, comm_stream=torch.cuda.Stream(device=dev))
             step = lambda: sb.process(data, Dz, vf, disp, velo)
-            plan = "%s tiles per rank brick" % (eng.plan_tiles(sb.bshape, sb.nd_local, periodic_box=False),)
+            if sb.zbricks:
+                plan = "one z-slab brick %s per rank, level-1 activations exchanged (sharding.py)" % (sb.bshape,)
+            else:
+                plan = "%s tiles per rank brick" % (eng.plan_tiles(sb.bshape, sb.nd_local, periodic_box=False),)
         # with --warmup 0 one priming pass still runs untimed: the first pass of a process plans the tiles and allocates
         # and zero-fills a ~200 GB workspace (seconds), which is set-up, not the hot path
         for _ in range(max(warmup, 1)):
