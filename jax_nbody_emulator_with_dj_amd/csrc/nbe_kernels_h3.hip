@@ -391,7 +391,9 @@ constexpr int UP_XC = 2 * 4 * UP_XV;                 // units of one resident ch
 constexpr int UP_MAXCH = 4;                          // Cin <= 64
 constexpr int UP_WS = 2 * 4 * 64;                    // units of one weight stage: (W, dW) x 4 units x 64 couts
 constexpr int UP_WBASE = UP_MAXCH * UP_XC;
-constexpr int UP_LDS_UNITS = UP_WBASE + 2 * UP_WS;   // 9216 units = 147,456 B
+constexpr int UP_RING = 4;                           // weight stages in flight: a stage is 18 MFMAs per wave (~0.3 us), an
+                                                     // 8 KB fetch from L2 takes longer -- with two buffers every stage waited for it
+constexpr int UP_LDS_UNITS = UP_WBASE + UP_RING * UP_WS;   // 10240 units = 163,840 B: all of the CU's LDS
 
 __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     f32x4* lds = lds_h3;
@@ -426,11 +428,14 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
         const int m = wave & 3;
         const char* src = (const char*)(d ? a.dw : a.w) + (long)p * a.set_stride +
                           (((long)ct * nchunk + c) * 256 + m * 64 + lane) * 16;
-        dma16((const float*)src, lds + UP_WBASE + (st & 1) * UP_WS + (d ? 256 : 0) + m * 64);
+        dma16((const float*)src, lds + UP_WBASE + (st % UP_RING) * UP_WS + (d ? 256 : 0) + m * 64);
     };
     dma_w(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // every wave issues exactly one DMA instruction per weight stage: stages st + 1 .. st + 3 stay in flight
+#pragma unroll
+    for (int k = 1; k < UP_RING; ++k) if (k < nstage) dma_w(k);
 
     f32x16 ym[2], yc[2], dm[2], dc[2];
     auto zero_acc = [&]() {
@@ -454,8 +459,7 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
 
     for (int st = 0; st < nstage; ++st) {
         const int p = st / nchunk, c = st - p * nchunk;
-        if (st + 1 < nstage) dma_w(st + 1);
-        const half8* wb = L8 + UP_WBASE + (st & 1) * UP_WS;
+        const half8* wb = L8 + UP_WBASE + (st % UP_RING) * UP_WS;
         const half8* xb = L8 + c * UP_XC;
         const int wo = (2 * lh) * 64 + 32 * it + li;
         const half8 wh = wb[wo], wl = wb[wo + 64], dwh = wb[256 + wo], dwl = wb[256 + wo + 64];
@@ -479,8 +483,13 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             h3_store2<true, true>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
             zero_acc();
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W(st + 1) has landed (stores included: they are few)
+        // W(st + 1) must have landed, W(st + 2) and W(st + 3) may stay in flight (vmcnt counts in issue order; the
+        // stores of a finished parity are younger than them and make this wait stricter, once in nchunk stages)
+        if (st + 3 < nstage) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        if (st + UP_RING < nstage) dma_w(st + UP_RING);          // into the slot stage st has just been read from
     }
 }
 

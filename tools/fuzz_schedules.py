@@ -1,5 +1,6 @@
 """Default engine schedule (merged tiles, z-slabs, periodic mode) against the reference-shaped one (the caller's grid,
-whole tensors, padded) on a handful of box shapes / models / arithmetic modes.  mid_chan 8 for speed."""
+whole tensors, padded) on a handful of box shapes / models / arithmetic modes.  mid_chan 8 and 16 for speed (16: the
+decoder's concat is read from two tensors, which needs mid_chan % 16 == 0)."""
 import os, sys, itertools
 import numpy as np
 sys.path.insert(0, ".")
@@ -11,15 +12,15 @@ Z, OM = 0.5, 0.3
 cases = [((64, 48, 56), (2, 1, 1)), ((96, 64, 48), (3, 1, 1)), ((48, 48, 48), (1, 1, 1)), ((128, 64, 64), (1, 2, 1)),
          ((72, 56, 48), (1, 1, 1)), ((40, 48, 64), (1, 1, 2)), ((160, 48, 48), (5, 1, 1)), ((56, 48, 48), (1, 1, 1))]
 worst = 0.0
-for prec in ("f16x3", "f32"):
+for prec, mid in itertools.product(("f16x3", "f32"), (8, 16)):
     os.environ["NBE_PRECISION"] = prec
     for vel, premod in itertools.product((True, False), (False, True)):
-        p = P.synthetic_params(seed=5, mid_chan=8)
+        p = P.synthetic_params(seed=5, mid_chan=mid)
         if premod:
             p = (J.modulate_emulator_parameters_vel if vel else J.modulate_emulator_parameters)(p, Z, OM)
         cls = {(True, False): J.StyleNBodyEmulatorVelCore, (False, False): J.StyleNBodyEmulatorCore,
                (True, True): J.NBodyEmulatorVelCore, (False, True): J.NBodyEmulatorCore}[(vel, premod)]
-        m = cls(mid_chan=8)
+        m = cls(mid_chan=mid)
         for size, ndiv in cases:
             box = np.random.default_rng(sum(size)).standard_normal((3,) + size).astype(np.float32)
             proc = J.SubboxProcessor(m, p, J.SubboxConfig(size=size, ndiv=ndiv))
@@ -38,6 +39,6 @@ for prec in ("f16x3", "f32"):
                 assert np.isfinite(g).all() and e < 1e-5, (prec, vel, premod, size, ndiv, name, e)
             for r, g in zip(got if vel else (got,), got2 if vel else (got2,)):
                 assert np.array_equal(r, g), ("slab 32 differs", prec, vel, premod, size, ndiv)
-            print(prec, "vel" if vel else "novel", "premod" if premod else "style", size, ndiv, "->", plan, "ok", flush=True)
+            print(prec, "mid", mid, "vel" if vel else "novel", "premod" if premod else "style", size, ndiv, "->", plan, "ok", flush=True)
         release_engines()
 print("all schedules agree; worst max|delta|/rms %.2e" % worst)
