@@ -380,20 +380,21 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
 // 2x up-sampling as ONE launch (f16x3, velocity)
 // ------------------------------------------------------------------------------------------------
 // StyleTransposeBase3DVel (style_layers_vel.py:234-269) is eight 1x1x1 GEMMs on the same input, one per output parity
-// (weight set p = 4 oz + 2 oy + ox).  Run as eight launches of conv_h3_kernel<MODE_FLAT1> the input is read eight
-// times and every launch writes every other 16-byte unit of the output rows: the two x parities of a row meet in
-// HBM as partial lines.  Here a workgroup keeps its 256 input positions x all Cin <= 64 channels (X and dX, hi and lo:
-// 128 KB) resident in LDS, streams the 8 x Cin/16 weight stages (8 KB each, double-buffered) and stores parity after
-// parity: the input is read once, and the partial lines of the x-parity pairs are written by the same workgroup
-// microseconds apart, where they merge in L2.  Same MFMA mapping and epilogue as conv_h3_kernel.
+// (weight set p = 4 oz + 2 oy + ox).  Run as eight launches of conv_h3_kernel<MODE_FLAT1> the input was read eight
+// times and every launch wrote every other 16-byte unit of the output rows.  Here a workgroup keeps its 256 input
+// positions x all Cin <= 64 channels (X and dX, hi and lo: 128 KB) resident in LDS and streams the weights.
+// A wave accumulates the TWO x parities of 32 positions side by side (the two accumulator tiles that conv_h3_kernel
+// gives to two column tiles): voxels 2x and 2x + 1 of an output row are then stored by the same wave within one
+// epilogue, and the row leaves L2 as whole lines.  (Parity after parity the second half of every line arrived ~100 us
+// after the first, long after L2 had turned over: WRITE_SIZE 1.5 x the algorithmic bytes, and the kernel ran at the
+// write bandwidth that pattern allows -- tools/micro/write_bw.hip: 4.7 TB/s for 32 interleaved plane streams.)
+// Stage = (position half, parity pair, chunk): weights of both parities, 16 KB, double-buffered.
 constexpr int UP_XV = 256;                           // positions per workgroup
 constexpr int UP_XC = 2 * 4 * UP_XV;                 // units of one resident chunk: (X, dX) x 4 units x 256
 constexpr int UP_MAXCH = 4;                          // Cin <= 64
-constexpr int UP_WS = 2 * 4 * 64;                    // units of one weight stage: (W, dW) x 4 units x 64 couts
+constexpr int UP_WS = 2 * 2 * 4 * 64;                // units of one weight stage: 2 parities x (W, dW) x 4 units x 64 couts
 constexpr int UP_WBASE = UP_MAXCH * UP_XC;
-constexpr int UP_RING = 4;                           // weight stages in flight: a stage is 18 MFMAs per wave (~0.3 us), an
-                                                     // 8 KB fetch from L2 takes longer -- with two buffers every stage waited for it
-constexpr int UP_LDS_UNITS = UP_WBASE + UP_RING * UP_WS;   // 10240 units = 163,840 B: all of the CU's LDS
+constexpr int UP_LDS_UNITS = UP_WBASE + 2 * UP_WS;   // 10240 units = 163,840 B: all of the CU's LDS
 
 __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     f32x4* lds = lds_h3;
@@ -402,11 +403,11 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int it = wave & 1, jq = wave >> 1;
+    const int it = wave & 1, jq = wave >> 1;                 // 32 couts, 32 of the 128 positions of a half
     const int tile = xcd_tile(blockIdx.x, a.ntiles);
     const int ct = blockIdx.y;
     const long q0 = (long)tile * UP_XV;
-    const int nchunk = a.nchunk, nstage = 8 * nchunk;
+    const int nchunk = a.nchunk, nstage = 2 * 4 * nchunk;    // stage = (half * 4 + pair) * nchunk + chunk
     const long HW = (long)a.H * a.W;
 
     // ---- resident activations: chunk c, tensor t, unit u (2 h + part), position v: lds[c * UP_XC + (t * 4 + u) * 256 + v]
@@ -421,23 +422,23 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             dma16((const float*)src, lds + c * UP_XC + (t * 4 + u) * UP_XV + qd * 64);
         }
     }
-    // ---- weights: stage st = p * nchunk + c  ->  set p, chunk c: 256 units of W, 256 of dW (one wave-instruction each per wave)
+    // ---- weights of stage st: parities 2 pp and 2 pp + 1 of chunk c: [parity][W | dW][unit 4][64 couts] = 16 wave-instructions
     auto dma_w = [&](int st) {
-        const int p = st / nchunk, c = st - p * nchunk;
-        const bool d = wave >= 4;
-        const int m = wave & 3;
-        const char* src = (const char*)(d ? a.dw : a.w) + (long)p * a.set_stride +
-                          (((long)ct * nchunk + c) * 256 + m * 64 + lane) * 16;
-        dma16((const float*)src, lds + UP_WBASE + (st % UP_RING) * UP_WS + (d ? 256 : 0) + m * 64);
+        const int c = st % nchunk, pp = (st / nchunk) & 3;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int n = wave + 8 * k;                       // 0..15: parity (n >> 3), set ((n >> 2) & 1), unit (n & 3)
+            const int par = n >> 3, d = (n >> 2) & 1, m = n & 3;
+            const char* src = (const char*)(d ? a.dw : a.w) + (long)(2 * pp + par) * a.set_stride +
+                              (((long)ct * nchunk + c) * 256 + m * 64 + lane) * 16;
+            dma16((const float*)src, lds + UP_WBASE + (st & 1) * UP_WS + n * 64);
+        }
     };
     dma_w(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // every wave issues exactly one DMA instruction per weight stage: stages st + 1 .. st + 3 stay in flight
-#pragma unroll
-    for (int k = 1; k < UP_RING; ++k) if (k < nstage) dma_w(k);
 
-    f32x16 ym[2], yc[2], dm[2], dc[2];
+    f32x16 ym[2], yc[2], dm[2], dc[2];                       // [x parity]
     auto zero_acc = [&]() {
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -445,28 +446,18 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             for (int e = 0; e < 16; ++e) { ym[jt][e] = 0.f; yc[jt][e] = 0.f; dm[jt][e] = 0.f; dc[jt][e] = 0.f; }
     };
     zero_acc();
-    // this lane's two input positions -> (z, y, x) once; the output voxel of parity p follows by shifts
-    int ob2[2];                                      // output voxel of parity 0 (< 2^31: tiles are <= 608^3 voxels)
-    bool ok[2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        const long q = q0 + jq * 64 + 32 * jt + li;
-        const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
-        const int yy = rem / a.W, xx = rem - yy * a.W;
-        ok[jt] = q < a.Q && xx < a.Wv && yy < a.Hv && z < a.Dv;
-        ob2[jt] = ok[jt] ? (2 * z * a.Ho + 2 * yy) * a.Wo + 2 * xx : 0;
-    }
 
     for (int st = 0; st < nstage; ++st) {
-        const int p = st / nchunk, c = st - p * nchunk;
-        const half8* wb = L8 + UP_WBASE + (st % UP_RING) * UP_WS;
+        const int c = st % nchunk, pp = (st / nchunk) & 3, half = st / (4 * nchunk);
+        if (st + 1 < nstage) dma_w(st + 1);
+        const half8* wb = L8 + UP_WBASE + (st & 1) * UP_WS;
         const half8* xb = L8 + c * UP_XC;
-        const int wo = (2 * lh) * 64 + 32 * it + li;
-        const half8 wh = wb[wo], wl = wb[wo + 64], dwh = wb[256 + wo], dwl = wb[256 + wo + 64];
+        const int xo = (2 * lh) * UP_XV + half * 128 + jq * 32 + li;
+        const half8 xh = xb[xo], xl = xb[xo + UP_XV], dxh = xb[4 * UP_XV + xo], dxl = xb[4 * UP_XV + xo + UP_XV];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            const int xo = (2 * lh) * UP_XV + jq * 64 + 32 * jt + li;
-            const half8 xh = xb[xo], xl = xb[xo + UP_XV], dxh = xb[4 * UP_XV + xo], dxl = xb[4 * UP_XV + xo + UP_XV];
+        for (int jt = 0; jt < 2; ++jt) {                      // x parity jt: its own weights, the same activations
+            const int wo = jt * 512 + (2 * lh) * 64 + 32 * it + li;
+            const half8 wh = wb[wo], wl = wb[wo + 64], dwh = wb[256 + wo], dwl = wb[256 + wo + 64];
             ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
             yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, yc[jt], 0, 0, 0);
             yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, yc[jt], 0, 0, 0);
@@ -477,19 +468,19 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxl, dc[jt], 0, 0, 0);
             dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dxh, dc[jt], 0, 0, 0);
         }
-        if (c == nchunk - 1) {                               // parity p is complete: store it, start the next
-            const int po = (((p >> 2) & 1) * a.Ho + ((p >> 1) & 1)) * a.Wo + (p & 1);      // this parity's shift (uniform)
-            const long o[2] = {(long)ob2[0] + (ok[0] ? po : 0), (long)ob2[1] + (ok[1] ? po : 0)};
+        if (c == nchunk - 1) {                               // the parity pair (oz, oy) = pp of this half is complete
+            const long q = q0 + half * 128 + jq * 32 + li;
+            const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
+            const int yy = rem / a.W, xx = rem - yy * a.W;
+            const bool okq = q < a.Q && xx < a.Wv && yy < a.Hv && z < a.Dv;
+            const long o0 = okq ? ((long)(2 * z + (pp >> 1)) * a.Ho + (2 * yy + (pp & 1))) * a.Wo + 2 * xx : 0;
+            const long o[2] = {o0, o0 + (okq ? 1 : 0)};
+            const bool ok[2] = {okq, okq};
             h3_store2<true, true>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
             zero_acc();
         }
-        // W(st + 1) must have landed, W(st + 2) and W(st + 3) may stay in flight (vmcnt counts in issue order; the
-        // stores of a finished parity are younger than them and make this wait stricter, once in nchunk stages)
-        if (st + 3 < nstage) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W(st + 1) has landed
         __syncthreads();
-        if (st + UP_RING < nstage) dma_w(st + UP_RING);          // into the slot stage st has just been read from
     }
 }
 
