@@ -206,7 +206,7 @@ def main():
             from jax_nbody_emulator_with_dj_amd import _lib
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             wl = traffic_key(precision, plan)
-            sub = {"conv_h3g": "conv_h3g_kernel<false>", "conv_h3n": "conv_h3g_kernel<true>", "conv_h3<FLAT3": "conv_h3q_kernel",
+            sub = {"conv_h3g": "conv_h3g_kernel<false,", "conv_h3n": "conv_h3g_kernel<true,", "conv_h3<FLAT3": "conv_h3q_kernel",
                    "conv_mfma_g": "conv_mfma_kernel"}
             key = next((v for k, v in sub.items() if dom["kernel"].startswith(k)), None)
             if tj.get("build") == _lib.source_hash() and tj.get("workload") == wl and key and world == 1:

@@ -1164,22 +1164,30 @@ static int launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
 // ([group][tap][unit][16 couts][8 ch], packed with cout_t = 16), a group of weights is 9 KB.  Each activation operand
 // then feeds one MFMA instead of two and the patch DMA is spread over a quarter of the MFMAs: the variant is bound by
 // the L2 -> LDS stream (about 2650 cycles per group against 1800 of MFMA), i.e. ~3.8 x faster than the wide tile.
-template <bool NARROW>
+// TALL (wide tile only): the wave tile is 64 couts x one patch row (4 x 2 MFMA tiles) instead of 32 couts x two rows
+// (2 x 4).  A product has two weight operands (hi, lo) but four activation operands (x, dx~, hi and lo each), so per tap
+// pair a wave reads 2 * MT + 4 * NT 16-byte operand sets from LDS: 20 for 2 x 4, 16 for 4 x 2 -- and on this chip, which
+// runs the kernel against its power limit, an LDS operand read costs 0.58 of an MFMA's energy
+// (tools/micro/mfma_power.hip, profiles/r02_mfma_power.txt), so bytes per MFMA are time.
+template <bool NARROW, bool TALL = false>
 struct HGGeom {
+    static_assert(!(NARROW && TALL), "the narrow tile has one row of MFMA tiles");
     static constexpr int CT = NARROW ? 16 : 64;             // couts per tile = rows of one weight unit in LDS
     static constexpr int TAPU = 4 * CT;                     // 16-byte units per tap
     static constexpr int WG = 9 * TAPU;                     // units of one group's weights (set w)
     static constexpr int XBASE = 2 * WG;                    // the two patch buffers follow the two weight buffers
     static constexpr int LDS_UNITS = XBASE + 2 * HQ_XB;
-    static constexpr int MT = NARROW ? 1 : 2, NT = NARROW ? 2 : 4, NTILE = MT * NT;   // MFMA tiles of a wave
+    static constexpr int MT = NARROW ? 1 : (TALL ? 4 : 2), NT = (NARROW || TALL) ? 2 : 4, NTILE = MT * NT;   // MFMA tiles of a wave
+    static constexpr bool ROWW = NARROW || TALL;            // a wave owns ONE row of the 8 x 32 patch (else two)
     static constexpr int NWI = WG / 64;                     // weight DMA wave-instructions per group: 36 / 9
     static constexpr int NWS = (NWI + 7) / 8;               // ... slots per wave: 5 / 2
 };
 static_assert(HGGeom<false>::XBASE == HQ_XBASE, "the two weight buffers fill exactly what conv_h3q_kernel uses for four");
 
-template <bool NARROW>
+template <bool NARROW, bool TALL>
 __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
-    typedef HGGeom<NARROW> G;
+    typedef HGGeom<NARROW, TALL> G;
+    constexpr bool ROWW = G::ROWW;
     constexpr int CT = G::CT, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = G::MT, NT = G::NT, NTILE = G::NTILE;
     constexpr int NWS = G::NWS;
 #if NBE_DBG   // phases as h3q_stamps: 0 prologue, 1 group up to its barrier, 2 own DMA, 3 barrier, 4 the three products after it, 7 epilogue
@@ -1266,18 +1274,18 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
     };
 
-    const int rowc = NARROW ? 0 : 32 * it;                       // first cout row of this wave inside the tile
-    const int rowp = NARROW ? wave : 2 * jq;                     // first patch row of this wave
+    const int rowc = ROWW ? 0 : 32 * it;                         // first cout row of this wave inside the tile
+    const int rowp = ROWW ? wave : 2 * jq;                       // first patch row of this wave
     const int aP = (ks * 4 + 2 * kh) * CT + rowc + c;
     const int bB = (2 * kh) * HQ_PP + rowp * HP_RS + c;
     const int bP1 = bB + ks, bP32 = bB + 32 * ks;
     auto LA = [&](half8 (&r)[MT], int idx) {
-        r[0] = L8[idx];
-        if (MT == 2) r[MT - 1] = L8[idx + 16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) r[mt] = L8[idx + 16 * mt];
     };
     auto LB = [&](half8 (&r)[NT], int idx) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) r[nt] = L8[idx + (NARROW ? 0 : (nt >> 1)) * HP_RS + 16 * (NARROW ? nt : (nt & 1))];
+        for (int nt = 0; nt < NT; ++nt) r[nt] = L8[idx + (ROWW ? 0 : (nt >> 1)) * HP_RS + 16 * (ROWW ? nt : (nt & 1))];
     };
     // one product on the wave tile: NTILE MFMAs; slot >= 0: DMA slots `slot`, `slot + 1` of group gn, one after each
     // MFMA row (wide) or both after the product (narrow)
@@ -1285,9 +1293,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
             mm(acc[t], A[t / NT], B[t % NT]);
-            if (slot >= 0 && (t % NT) == NT - 1) {
+            if (slot >= 0 && (NTILE == 8 ? (t % 4) == 3 : t == NTILE - 1)) {
                 if (px) {
-                    if (MT == 2) dma_slot(slot + t / NT, nb);
+                    if (NTILE == 8) dma_slot(slot + t / 4, nb);
                     else { dma_slot(slot, nb); dma_slot(slot + 1, nb); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1384,22 +1392,27 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
             half8 a1w[MT], a0[MT], a1d[MT], a0d[MT], b1x[NT], b1d[NT];
             const int aS1 = wb + (2 * kh + ks) * CT + rowc + c, aS0 = wb + (2 * kh) * CT + rowc + c;
             const int bS1 = xb + (2 * kh + 1 - ks) * HQ_PP + rowp * HP_RS + c + SH4;
-            LA(a1w, aS1); LB(b1x, bS1); LA(a0, aS0); LB(b1d, bS1 + HQ_XT); LA(a1d, aS1 + 4 * CT); LA(a0d, aS0 + 4 * CT);
-            {
-                const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            LA(a1w, aS1); LB(b1x, bS1); LA(a0, aS0); LB(b1d, bS1 + HQ_XT);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { a0[mt] = ks ? a0[mt] : zero; a0d[mt] = ks ? a0d[mt] : zero; }
-            }
+            for (int mt = 0; mt < MT; ++mt) a0[mt] = ks ? a0[mt] : zero;
             NBE_SB; MM8(yc, a1w, b1x, 0, nb, px); NBE_SB;                    // W_s.x, correction terms
-            MM8(ym, a0, b1x, 2, nb, px); NBE_SB;                             //        main term
+            LA(a1d, aS1 + 4 * CT);                                           // (the dW_s~ operands follow as registers free up)
+            NBE_SB; MM8(ym, a0, b1x, 2, nb, px); NBE_SB;                     //        main term
             if (!(a.flags & F_SKIP_NODX)) {                                  // (conv_l00: the input field has no tangent)
                 MM8(dc, a1w, b1d, 4, nb, px); NBE_SB;                        // W_s.dx~
-                MM8(dm, a0, b1d, 6, nb, px); NBE_SB;
-            } else if (px) {
+                LA(a0d, aS0 + 4 * CT);
+                NBE_SB; MM8(dm, a0, b1d, 6, nb, px); NBE_SB;
+            } else {
+                LA(a0d, aS0 + 4 * CT);
+                if (px) {
 #pragma unroll
-                for (int k = 4; k < 8; ++k) dma_slot(k, nb);
+                    for (int k = 4; k < 8; ++k) dma_slot(k, nb);
+                }
             }
-            MM8(dc, a1d, b1x, 8, nb, px); NBE_SB;                            // dW_s~.x
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a0d[mt] = ks ? a0d[mt] : zero;
+            NBE_SB; MM8(dc, a1d, b1x, 8, nb, px); NBE_SB;                    // dW_s~.x
             MM8(dm, a0d, b1x, 10, nb, px); NBE_SB;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -1410,74 +1423,74 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     // ---- epilogue (layout and load-first order of conv_h3q_kernel): y = W.x + b, dy = W.dx~ + beta * (W.x)
     {
         const bool act = a.flags & F_ACT, res = a.flags & F_RES, gauge = a.gout != nullptr;
-        int unit[MT];
-        bool uok[MT];
-        f32x4 bv[MT], be[MT], gv[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            unit[mt] = ct * (CT / 8) + (NARROW ? 0 : 4 * it) + 2 * mt + ks;
-            uok[mt] = unit[mt] < a.cout_groups;
-            if (!uok[mt]) unit[mt] = a.cout_groups - 1;
-            bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
-            be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
-            if (gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
-        }
         int o[NT];                                               // voxel index in the output planes (< 2^31: tiles are <= 608^3)
         bool ook[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int yy = y0 + rowp + (NARROW ? 0 : (nt >> 1)), xx = x0 + 16 * (NARROW ? nt : (nt & 1)) + c;
+            const int yy = y0 + rowp + (ROWW ? 0 : (nt >> 1)), xx = x0 + 16 * (ROWW ? nt : (nt & 1)) + c;
             ook[nt] = yy < a.Hv && xx < a.Wv;
             o[nt] = ook[nt] ? (z * a.Ho + yy) * a.Wo + xx : z * a.Ho * a.Wo;
         }
-        half4 rh[NTILE], rl[NTILE], dh[NTILE], dl[NTILE];
-        if (res) {
+        // one row of MFMA tiles (16 couts = 2 units) at a time: its per-channel vectors, the residuals of its NT tiles
+        // (loads first), then the tiles -- all MT rows at once do not fit the registers of the 4 x 2 wave tile
 #pragma unroll
-            for (int t = 0; t < NTILE; ++t) {
-                const long rb = ((long)(2 * unit[t / NT]) * a.res_pstride + (long)o[t % NT]) * 16 + 8 * kh;
-                const long rl_ = rb + a.res_pstride * 16;
-                rh[t] = *(const half4*)((const char*)a.r + rb);
-                rl[t] = *(const half4*)((const char*)a.r + rl_);
-                dh[t] = *(const half4*)((const char*)a.dr + rb);
-                dl[t] = *(const half4*)((const char*)a.dr + rl_);
-            }
-        }
+        for (int mt = 0; mt < MT; ++mt) {
+            int unit = ct * (CT / 8) + (ROWW ? 0 : 4 * it) + 2 * mt + ks;
+            const bool uok = unit < a.cout_groups;
+            if (!uok) unit = a.cout_groups - 1;
+            const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * kh);
+            const f32x4 be = *(const f32x4*)(a.beta + unit * 8 + 4 * kh);
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+            if (gauge) gv = *(const f32x4*)(a.gout + unit * 8 + 4 * kh);
+            half4 rh[NT], rl[NT], dh[NT], dl[NT];
+            if (res) {
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) {
-            const int mt = t / NT, nt = t % NT;
-            f32x4 v, dv;
-            // the accumulators leave their AGPRs tile by tile, here: copied out wholesale at the top of the epilogue (what
-            // the compiler does by itself) they do not fit beside the residuals and spill, and a scratch reload among
-            // the stores waits for every store before it
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float yp = acc_read(ym[t][e]) + acc_read(yc[t][e]) * H3_INV;
-                v[e] = yp + bv[mt][e];
-                dv[e] = acc_read(dm[t][e]) + acc_read(dc[t][e]) * H3_INV + be[mt][e] * yp;
-            }
-            if (res) { v += join4(rh[t], rl[t]); dv += join4(dh[t], dl[t]); }
-            if (act) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
-                    v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                for (int nt = 0; nt < NT; ++nt) {
+                    const long rb = ((long)(2 * unit) * a.res_pstride + (long)o[nt]) * 16 + 8 * kh;
+                    const long rl_ = rb + a.res_pstride * 16;
+                    rh[nt] = *(const half4*)((const char*)a.r + rb);
+                    rl[nt] = *(const half4*)((const char*)a.r + rl_);
+                    dh[nt] = *(const half4*)((const char*)a.dr + rb);
+                    dl[nt] = *(const half4*)((const char*)a.dr + rl_);
                 }
             }
-            if (gauge) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
-            }
-            if (uok[mt] && ook[nt]) {
-                const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
-                const long ol = ob + a.out_pstride * 16;
-                half4 hi, lo;
-                split4(v, hi, lo);
-                *(half4*)((char*)a.y + ob) = hi;
-                *(half4*)((char*)a.y + ol) = lo;
-                split4(dv, hi, lo);
-                *(half4*)((char*)a.dy + ob) = hi;
-                *(half4*)((char*)a.dy + ol) = lo;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int t = mt * NT + nt;
+                f32x4 v, dv;
+                // the accumulators leave their AGPRs tile by tile, here: copied out wholesale at the top of the epilogue
+                // (what the compiler does by itself) they do not fit beside the residuals and spill, and a scratch
+                // reload among the stores waits for every store before it
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yp = acc_read(ym[t][e]) + acc_read(yc[t][e]) * H3_INV;
+                    v[e] = yp + bv[e];
+                    dv[e] = acc_read(dm[t][e]) + acc_read(dc[t][e]) * H3_INV + be[e] * yp;
+                }
+                if (res) { v += join4(rh[nt], rl[nt]); dv += join4(dh[nt], dl[nt]); }
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                        v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                    }
+                }
+                if (gauge) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += gv[e] * v[e];
+                }
+                if (uok && ook[nt]) {
+                    const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
+                    const long ol = ob + a.out_pstride * 16;
+                    half4 hi, lo;
+                    split4(v, hi, lo);
+                    *(half4*)((char*)a.y + ob) = hi;
+                    *(half4*)((char*)a.y + ol) = lo;
+                    split4(dv, hi, lo);
+                    *(half4*)((char*)a.dy + ob) = hi;
+                    *(half4*)((char*)a.dy + ol) = lo;
+                }
             }
         }
     }
@@ -1493,14 +1506,14 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 #undef NBE_STAMP
 }
 
-template <bool NARROW>
+template <bool NARROW, bool TALL>
 static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
-    typedef HGGeom<NARROW> G;
+    typedef HGGeom<NARROW, TALL> G;
     constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_h3g_kernel<NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3g_kernel<NARROW, TALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
@@ -1526,7 +1539,7 @@ static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
     }
     ka.dws_delta = nskip ? (const char*)ka.dws - (const char*)ka.ws : 0;
     dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
-    hipLaunchKernelGGL(conv_h3g_kernel<NARROW>, grid, block, smem, s, ka);
+    hipLaunchKernelGGL((conv_h3g_kernel<NARROW, TALL>), grid, block, smem, s, ka);
     return 0;
 }
 
@@ -1893,7 +1906,11 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     static const bool shape32 = getenv("NBE_H3_SHAPE") && atoi(getenv("NBE_H3_SHAPE")) == 32;   // A/B: 32x32x16 MFMAs
     if (ka.beta) {                                               // gauged input tangent: only conv_h3g_kernel reads it
         if (!(pw.mode == MODE_FLAT3 && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) return 1;   // no gauged kernel
-        if (split) return pw.cout_t == 16 ? launch_h3g<true>(ka, ct, s) : launch_h3g<false>(ka, ct, s);
+        if (split) {
+            static const bool tall = !(getenv("NBE_H3G_TALL") && atoi(getenv("NBE_H3G_TALL")) == 0);   // A/B switch, default on
+            if (pw.cout_t == 16) return launch_h3g<true, false>(ka, ct, s);
+            return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
+        }
         return launch_h2q<false, true>(ka, ct, s);
     }
     // A/B switch (NBE_L0_FLAT=1): the first layer (no input tangent, Cin = 3 padded to 16; 64 channels x (hi, lo) x (y, dy)
