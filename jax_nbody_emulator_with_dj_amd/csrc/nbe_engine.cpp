@@ -384,6 +384,8 @@ static void prof_collect(nbe_ctx* c) {
 static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false, bool up8 = false) {
     if (up8) return "up_h3<8 parities,vel,dx>";
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
+    static const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);
+    if (stem_on && pw.stem && vel && !has_dx && pw.mode == MODE_FLAT3) return "stem_h3<FLAT3,vel,nodx>";
     char b[96];
     if (g6 && prec_is_half(pw.prec)) snprintf(b, sizeof b, "%s<%s,vel,dx>", pw.prec == PREC_F16 ? "conv_h1g" : (pw.cout_t == 16 ? "conv_h3n" : "conv_h3g"), m);
     else if (g6) snprintf(b, sizeof b, "conv_mfma_g<%s,vel,dx,ni%d>", m, pw.ni);
@@ -1185,7 +1187,7 @@ static void free_layers(nbe_ctx* c) {
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
-        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pwn.w); (void)hipFree(L.pwn.dw); (void)hipFree(L.bias_f);
+        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pw.stem); (void)hipFree(L.pwn.w); (void)hipFree(L.pwn.dw); (void)hipFree(L.bias_f);
         (void)hipFree(L.alpha); (void)hipFree(L.beta);
     }
     c->layers.clear();
@@ -1424,6 +1426,9 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             HIPCHK(hipMalloc((void**)&pn.w, pn.floats * 4));
             if (L.kind == 1) HIPCHK(hipMalloc((void**)&pn.dw, pn.floats * 4));   // a skip that runs inside the narrow conv_1
         }
+        // the first layer in its own packing (stem_h3_kernel): K = 27 taps x 3 channels = 81 <= 96
+        if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && L.first && d.cin <= 3 && d.cout <= 64)
+            HIPCHK(hipMalloc((void**)&pw.stem, 4 * 3 * 4 * 64 * 16));
         HIPCHK(hipMalloc((void**)&L.bias0, nb * 4));
         HIPCHK(hipMemcpy(L.bias0, pw.bias, nb * 4, hipMemcpyDeviceToDevice));
         for (int i = 0; i < d.cout; ++i)
@@ -2170,6 +2175,8 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
 #define TCHK(e) if ((e) != hipSuccess) { rc = fail("hip error in nbe_test_layer: %s", hipGetErrorString(hipGetLastError())); break; }
         TCHK(hipMalloc((void**)&pw.w, pw.floats * pw.nsets * 4));
         if (vel) TCHK(hipMalloc((void**)&pw.dw, pw.floats * pw.nsets * 4));
+        if (c->prec == PREC_F16X3 && vel && kind == 0 && !has_dx && cin <= 3 && cout <= 64)     // as conv_l00/conv_0: stem_h3_kernel
+            TCHK(hipMalloc((void**)&pw.stem, 4 * 3 * 4 * 64 * 16));
         const int nb = pw.ctiles * 32 * pw.ni;
         TCHK(hipMalloc((void**)&pw.bias, nb * 4)); TCHK(hipMemset(pw.bias, 0, nb * 4));
         TCHK(hipMemcpy(pw.bias, bias, cout * 4, hipMemcpyHostToDevice));
@@ -2244,7 +2251,7 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
     } while (0);
     c->vel = saved_vel;
     (void)hipFree(dxin); (void)hipFree(ddx); (void)hipFree(dwt); (void)hipFree(ddw); (void)hipFree(dout); (void)hipFree(ws);
-    (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias);
+    (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.pw.stem);
     return rc;
 }
 

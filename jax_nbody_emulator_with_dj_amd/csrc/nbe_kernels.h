@@ -61,6 +61,7 @@ struct PackedW {
     int ctiles = 0;          // cout tiles
     int64_t floats = 0;      // size of w (and dw) in floats, per parity set
     int nsets = 1;           // 8 for the up-sample layer (one set per output parity)
+    float* stem = nullptr;   // f16x3 + velocity, conv_l00/conv_0 only: [W hi | W lo | dW hi | dW lo] x 96 k x 64 couts (stem_h3_kernel)
 };
 
 struct ConvLaunch {

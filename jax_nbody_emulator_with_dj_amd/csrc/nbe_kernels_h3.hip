@@ -1892,12 +1892,215 @@ static void launch_h3p_v(const ConvKArgs& ka, int ct, hipStream_t s) { launch_h3
 template <int MODE, int XDEPTH, bool SPLIT, bool VEL, bool HAS_DX>
 static void launch_h3_v(const ConvKArgs& ka, int ct, hipStream_t s) { launch_h3_t<MODE, VEL, HAS_DX, XDEPTH, SPLIT>(ka, ct, s); }
 
+// ------------------------------------------------------------------------------------------------
+// The first layer (conv_l00/conv_0: Cin = 3, no input tangent; style_nbody_emulator_vel_core.py:132-143) -- f16x3, velocity
+// ------------------------------------------------------------------------------------------------
+// On the general kernels the three input channels are a 16-channel chunk: K = 27 taps x 16 = 432 where 81 are real, and the
+// layer was bound by those MFMAs (43 % matrix-busy, 9.1 ms per launch for a layer that only has to write its output).
+// Here K = (tap, channel) = 81, padded to 96 = three k-steps of v_mfma_f32_16x16x32_f16: the workgroup keeps the weights
+// ([W hi | W lo | dW hi | dW lo] x 96 x 64 couts = 48 KB) in LDS for its whole life, stages the 6 x 34 x 3 input patch of a
+// 4 x 32 output tile as nine small f16 planes per part (part, channel, dz), and every lane GATHERS its B operand
+// (8 consecutive k of one position) with 16-bit LDS reads at offsets it computed once.  18 MFMAs per 16 x 16 output tile
+// where the general kernel issued 81.  Wave w owns row w of the tile: 64 couts x 32 positions, 128 accumulator registers.
+// Workgroups are persistent (grid = 2 per CU, tile = blockIdx.x + n gridDim.x: the tiles in flight are neighbours), patches
+// double-buffered: one barrier per tile, the next tile's 12 bytes per patch voxel are fetched under the MFMAs.
+// y = W.x + b, dy = dW.x; LeakyReLU, output gauge, hi/lo split and stores as in conv_h3g_kernel.
+constexpr int ST_ROWS = 4;
+constexpr int ST_PL = (ST_ROWS + 2) * HP_RS;                 // halves of one (part, channel, dz) patch plane: 6 x 34 = 204
+constexpr int ST_PV = 3 * ST_PL;                             // patch voxels of a tile: 612
+constexpr int ST_PATCH = 3680;                               // 2 parts x 3 channels x 3 dz planes = 3672 halves, rounded to 16 B
+constexpr int ST_WU = 4 * 3 * 4 * 64;                        // weight units: [set 4][k-step 3][k-block 4][64 couts] x 8 halves
+constexpr size_t ST_LDS = (size_t)ST_WU * 16 + 2 * ST_PATCH * 2;   // 63,872 B: two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
+    f32x4* lds = lds_h3;
+    const half8* L8 = (const half8*)lds_h3;
+    _Float16* P = (_Float16*)(lds_h3 + ST_WU);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
+
+    // weights: 48 wave-instructions of 1 KB, 12 per wave
+#pragma unroll
+    for (int k = 0; k < 12; ++k) dma16(a.stem_w + ((long)(wave * 12 + k) * 64 + lane) * 4, lds + (wave * 12 + k) * 64);
+
+    // this lane's B-operand gather: element j of k-step s is k = 32 s + 8 q + j = 3 tap + channel
+    int off[3][8];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * s + 8 * q + j;
+            const int tap = k / 3, ch = k - 3 * tap, dz = tap / 9, r = tap - 9 * dz, dy = r / 3, dx = r - 3 * dy;
+            off[s][j] = k < 81 ? (ch * 3 + dz) * ST_PL + dy * HP_RS + dx : 0;     // k >= 81: zero weights, any finite value
+        }
+
+    const int tnx = a.tnx, tny = a.tny, ntiles = a.ntiles;
+    // patch voxels of this thread: pv = tid, tid + 256, tid + 512 (< 612)
+    int prow[3], pcol[3], pdz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int pv = min(tid + 256 * i, ST_PV - 1);
+        pdz[i] = pv / ST_PL;
+        const int r = pv - pdz[i] * ST_PL;
+        prow[i] = r / HP_RS; pcol[i] = r - prow[i] * HP_RS;
+    }
+    half4 ph[3], pl[3];
+    auto fetch = [&](int tile) {                                 // global -> registers: 4 halves (3 channels) of hi and of lo
+        const int tx = tile % tnx, t2 = tile / tnx, ty = t2 % tny, z = t2 / tny;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int yy = min(ty * ST_ROWS + prow[i], a.H - 1), xx = min(tx * HP_COLS + pcol[i], a.W - 1);
+            const long v = ((long)(z + pdz[i]) * a.H + yy) * a.W + xx;
+            ph[i] = *(const half4*)(a.x + v * 4);
+            pl[i] = *(const half4*)(a.x + (a.in_pstride + v) * 4);
+        }
+    };
+    auto stage = [&](int buf) {                                  // registers -> LDS planes [part][channel][dz][row][col]
+        _Float16* Pb = P + buf * ST_PATCH;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pv = tid + 256 * i;
+            if (pv < ST_PV) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    Pb[ch * ST_PV + pv] = ph[i][ch];
+                    Pb[(3 + ch) * ST_PV + pv] = pl[i][ch];
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the weights (and the first patch)
+    const int rb = wave * HP_RS + c;
+    const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
+    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        stage(buf);
+        __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) fetch(nxt);
+
+        f32x4 ym[8], yc[8], dm[8], dc[8];                        // tile t = 2 mt + nt
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ym[t][e] = 0.f; yc[t][e] = 0.f; dm[t][e] = 0.f; dc[t][e] = 0.f; }
+        const _Float16* Pb = P + buf * ST_PATCH + rb;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            half8 xh[2], xl[2], A[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    xh[nt][j] = Pb[off[s][j] + 16 * nt];
+                    xl[nt][j] = Pb[off[s][j] + 16 * nt + 3 * ST_PV];
+                }
+            auto LA = [&](int set) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) A[mt] = L8[((set * 3 + s) * 4 + q) * 64 + 16 * mt + c];
+            };
+            auto MM = [&](f32x4 (&acc)[8], const half8 (&B)[2]) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t >> 1], B[t & 1], acc[t], 0, 0, 0);
+            };
+            LA(0); MM(yc, xl); MM(ym, xh);                        // W hi
+            LA(1); MM(yc, xh);                                    // W lo
+            LA(2); MM(dc, xl); MM(dm, xh);                        // dW hi
+            LA(3); MM(dc, xh);                                    // dW lo
+        }
+
+        // epilogue: lane (c, q) holds couts 16 mt + 4 q + e of position (row wave, col 16 nt + c)
+        const int tx = tile % tnx, t2 = tile / tnx, ty = t2 % tny, z = t2 / tny;
+        const int yy = ty * ST_ROWS + wave;
+        long o[2];
+        bool ook[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int xx = tx * HP_COLS + 16 * nt + c;
+            ook[nt] = yy < a.Hv && xx < a.Wv;
+            o[nt] = ook[nt] ? ((long)z * a.Ho + yy) * a.Wo + xx : 0;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int unit = 2 * mt + ks;
+            const bool uok = unit < a.cout_groups;
+            if (!uok) unit = a.cout_groups - 1;
+            const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * kh);
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+            if (gauge) gv = *(const f32x4*)(a.gout + unit * 8 + 4 * kh);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int t = 2 * mt + nt;
+                f32x4 v, dv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = ym[t][e] + yc[t][e] * H3_INV + bv[e];
+                    dv[e] = dm[t][e] + dc[t][e] * H3_INV;
+                }
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                        v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                    }
+                }
+                if (gauge) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += gv[e] * v[e];
+                }
+                if (uok && ook[nt]) {
+                    const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + o[nt]) * 16 + 8 * kh;
+                    const long ol = ob + a.out_pstride * 16;
+                    half4 hi, lo;
+                    split4(v, hi, lo);
+                    *(half4*)((char*)a.y + ob) = hi;
+                    *(half4*)((char*)a.y + ol) = lo;
+                    split4(dv, hi, lo);
+                    *(half4*)((char*)a.dy + ob) = hi;
+                    *(half4*)((char*)a.dy + ol) = lo;
+                }
+            }
+        }
+    }
+}
+
+static int launch_stem(ConvKArgs ka, hipStream_t s) {
+    ka.tny = (ka.Hv + ST_ROWS - 1) / ST_ROWS;
+    ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
+    const long nt = (long)ka.Dv * ka.tny * ka.tnx;
+    if (nt <= 0 || nt >= (1L << 31) || ka.cout_groups > 8 || ka.nchunk != 1) return 1;
+    ka.ntiles = (int)nt;
+    const int grid = (int)std::min<long>(nt, 512);
+    hipLaunchKernelGGL(stem_h3_kernel, dim3(grid), dim3(256), ST_LDS, s, ka);
+    return 0;
+}
+
+// stem_w: [set: W hi, W lo, dW hi, dW lo][k-step 3][k-block 4][cout 64][j 8], k = 32 s + 8 q + j = 3 tap + channel
+__global__ __launch_bounds__(256) void pack_stem_kernel(const float* __restrict__ w, int cout, int cin, _Float16* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over [part 2][s 3][q 4][co 64][j 8]
+    if (idx >= 2 * 3 * 4 * 64 * 8) return;
+    const int j = idx & 7, co = (idx >> 3) & 63, qq = (idx >> 9) & 3, sp = idx >> 11, st = sp % 3, part = sp / 3;
+    const int k = 32 * st + 8 * qq + j, tap = k / 3, ch = k - 3 * tap;
+    float v = 0.f;
+    if (k < 81 && ch < cin && co < cout) v = w[((size_t)co * cin + ch) * 27 + tap];
+    const _Float16 hi = (_Float16)v;
+    dst[idx] = part == 0 ? hi : (_Float16)((v - (float)hi) * H3_SCALE);
+}
+
 int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
     const int ct = pw.ctiles;
     static const int depth = (getenv("NBE_H3_DEPTH") && atoi(getenv("NBE_H3_DEPTH")) == 3) ? 3 : 2;
     static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
     static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
     const bool split = pw.prec == PREC_F16X3;
+    static const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);         // A/B switch, default on
+    if (stem_on && ka.stem_w && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
+        !(ka.flags & F_RES) && ka.nskip == 0 && !ka.beta)
+        return launch_stem(ka, s);
     // a second input segment / a fused skip exist only in the wide gauged f16x3 kernel
     if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split)) return 1;
 #define NBE_VD(F, ...)                                                          \
@@ -1978,6 +2181,9 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
 }
 
 void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s) {
+    if (pw.stem && kind == 0 && (dst == pw.w || dst == pw.dw))      // the first layer's own format beside the general one
+        hipLaunchKernelGGL(pack_stem_kernel, dim3(48), dim3(256), 0, s, w_oidhw, cout, cin,
+                           (_Float16*)pw.stem + (dst == pw.dw ? 2 * 3 * 4 * 64 * 8 : 0));
     const long halves = pw.floats * 2;
     const long total = halves * pw.nsets;
     hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,

@@ -69,6 +69,9 @@ CASES = [
     ("conv3", 64, 64, (9, 13, 21), True, True, False, 0),
     ("conv3", 64, 64, (7, 10, 40), True, True, True, 0),
     ("conv3", 3, 64, (10, 11, 19), False, True, False, 0),      # first layer: no input tangent
+    ("conv3", 3, 64, (20, 40, 100), False, True, False, 0),     # ... more tiles than persistent workgroups (stem_h3_kernel)
+    ("conv3", 3, 8, (6, 9, 35), False, False, False, 0),        # ... of a narrow test model, ragged tile edges
+    ("conv3", 2, 16, (5, 7, 37), False, True, False, 0),
     ("conv3", 64, 3, (8, 9, 18), True, False, True, 0),         # head: Cout=3, residual, no act
     ("conv3", 128, 128, (6, 7, 20), True, True, False, 0),
     ("conv3", 128, 64, (6, 9, 15), True, True, True, 0),
