@@ -18,6 +18,7 @@ cd $R
 python3 tools/pmc_traffic.py gpurun_out/prof_fetch gpurun_out/prof_write --json gpurun_out/traffic.json --bench-json gpurun_out/r02_bench_pmc_fetch.json > gpurun_out/r02_pmc_fetch_write.txt 2>&1
 python3 tools/pmc_summary.py gpurun_out/prof_sq conv_h3 > gpurun_out/r02_pmc_sq.txt 2>&1
 python3 tools/pmc_summary.py gpurun_out/prof_sq up_h3 >> gpurun_out/r02_pmc_sq.txt 2>&1
+python3 tools/pmc_summary.py gpurun_out/prof_sq stem_h3 >> gpurun_out/r02_pmc_sq.txt 2>&1
 f=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r02_bench_kernel_stats.csv
 head -12 gpurun_out/r02_pmc_fetch_write.txt; cat gpurun_out/r02_pmc_sq.txt; head -8 gpurun_out/r02_bench_kernel_stats.csv | cut -c1-200
 # keep the merge small: the raw traces stay on the box
