@@ -384,7 +384,7 @@ static void prof_collect(nbe_ctx* c) {
 static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false, bool up8 = false) {
     if (up8) return "up_h3<8 parities,vel,dx>";
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
-    static const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);
+    const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);
     if (stem_on && pw.stem && vel && !has_dx && pw.mode == MODE_FLAT3) return "stem_h3<FLAT3,vel,nodx>";
     char b[96];
     if (g6 && prec_is_half(pw.prec)) snprintf(b, sizeof b, "%s<%s,vel,dx>", pw.prec == PREC_F16 ? "conv_h1g" : (pw.cout_t == 16 ? "conv_h3n" : "conv_h3g"), m);
@@ -396,7 +396,7 @@ static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 =
     return b;
 }
 
-static bool narrow_off() { static const bool v = getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0; return v; }   // A/B switch
+static bool narrow_off() { return getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0; }   // A/B switch (set before the context is created)
 static bool narrow_tile(const Layer* L) { return L->pwn.w && !narrow_off(); }
 
 // launch one convolution layer (or record it in a dry run)
@@ -568,7 +568,7 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
     if (cat.p.D != 2 * x.p.D || cat.p.H - 2 * cat.pad != 2 * Hx || cat.p.W - 2 * cat.pad != 2 * Wx)
         return fail("internal: concat geometry mismatch in %s", name);
     // f16x3 with velocity and Cin <= 64: all eight parities in one launch (up_h3_kernel: the input is read once)
-    static const bool up8_off = getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0;          // A/B switch
+    const bool up8_off = getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0;                 // A/B switch
     const bool up8 = c->prec == PREC_F16X3 && c->vel && L->pw.cin_pad <= 64 && !up8_off;
     for (int p = 0; p < (up8 ? 1 : 8); ++p) {
         ConvLaunch cl; cl.in = x.p; cl.in_off = ((int64_t)xcrop * x.p.W + xcrop);

@@ -917,6 +917,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     auto mm = [&](f32x4& acc, const half8& A, const half8& B) {
         asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
     };
+    // the same behind a VALU select: the compiler does not see an MFMA inside an asm statement and leaves out the two wait
+    // states the ISA wants between a VALU write of a VGPR and an MFMA that reads it (tools/check_mfma_hazards.py)
+    auto mmz = [&](f32x4& acc, const half8& A, const half8& B) {
+        asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+    };
 
     // ---- operands.  A (2 MFMA row tiles): unit (tap, 2*kh + part) of the stage's weight buffer, row 32*it + 16*mt + c.
     // B (4 column tiles): patch plane 2*kh + part, position (2*jq + jt, 16*nh + c) shifted by this lane group's tap.
@@ -936,9 +941,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
     // patch of the next group.  (Issuing both patches in the first stage and leaving them in flight across its
     // barrier with a counted vmcnt was measured on one device: dx only -0.6 %, x and dx -2.5 %.)
     auto MM8 = [&](f32x4 (&acc)[8], const half8 (&A)[2], const half8 (&B)[4], int kind, int slot, int g, int gn,
-                   long xo, int nb, bool px) {
+                   long xo, int nb, bool px, bool zsel = false /* A comes out of a VALU select */) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
+            if (zsel && (t & 3) == 0) mmz(acc[t], A[t >> 2], B[t & 3]); else
             mm(acc[t], A[t >> 2], B[t & 3]);
             if (kind != 0 && (t & 3) == 3) {
                 const int k = slot + (t >> 2);
@@ -1025,7 +1031,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3q_kernel(ConvKArgs a) {
         }
         NBE_SB; MM8(yc, a1w, b1x, 0, 0, g, gn, xo, nb, px); NBE_SB;          // wh.xl + wl.xh
         LB(b1d, bS1 + HQ_XT);
-        NBE_SB; MM8(ym, a0, b1x, 0, 0, g, gn, xo, nb, px); NBE_SB;           // wh.xh
+        NBE_SB; MM8(ym, a0, b1x, 0, 0, g, gn, xo, nb, px, true); NBE_SB;     // wh.xh
         LB(xl, xb + SH5 + bP32 + HQ_PP);                                 // x of taps (5,6): this group's patch
         NBE_SB; MM8(dm, a2, b2, 0, 0, g, gn, xo, nb, px); NBE_SB;            // dwh.xh + wh.dxh
         LB(xh, xb + SH5 + bP32);
@@ -1273,6 +1279,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     auto mm = [&](f32x4& acc, const half8& A, const half8& B) {
         asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
     };
+    // the same behind a VALU select: the compiler does not see an MFMA inside an asm statement and leaves out the two wait
+    // states the ISA wants between a VALU write of a VGPR and an MFMA that reads it (tools/check_mfma_hazards.py)
+    auto mmz = [&](f32x4& acc, const half8& A, const half8& B) {
+        asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+    };
 
     const int rowc = ROWW ? 0 : 32 * it;                         // first cout row of this wave inside the tile
     const int rowp = ROWW ? wave : 2 * jq;                       // first patch row of this wave
@@ -1289,9 +1300,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
     };
     // one product on the wave tile: NTILE MFMAs; slot >= 0: DMA slots `slot`, `slot + 1` of group gn, one after each
     // MFMA row (wide) or both after the product (narrow)
-    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px) {
+    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px,
+                   bool zsel = false /* A comes out of a VALU select */) {
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
+            if (zsel && (t % NT) == 0) mmz(acc[t], A[t / NT], B[t % NT]); else
             mm(acc[t], A[t / NT], B[t % NT]);
             if (slot >= 0 && (NTILE == 8 ? (t % 4) == 3 : t == NTILE - 1)) {
                 if (px) {
@@ -1358,10 +1371,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         }
         NBE_SB; MM8(yc, a1w, b1x, -1, 0, false); NBE_SB;                     // wh.xl + wl.xh
         LB(xl, xb + SH5 + bP32 + HQ_PP);
-        NBE_SB; MM8(ym, a0, b1x, -1, 0, false); NBE_SB;                      // wh.xh
+        NBE_SB; MM8(ym, a0, b1x, -1, 0, false, true); NBE_SB;                // wh.xh
         LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
         NBE_SB; MM8(dc, a1w, b1d, -1, 0, false); NBE_SB;                     // wh.dxl + wl.dxh
-        MM8(dm, a0, b1d, -1, 0, false); NBE_SB;                              // wh.dxh
+        MM8(dm, a0, b1d, -1, 0, false, true); NBE_SB;                        // wh.dxh
         pair(-1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                               // taps (5,6)
              [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
              [&] {});
@@ -1398,11 +1411,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
             for (int mt = 0; mt < MT; ++mt) a0[mt] = ks ? a0[mt] : zero;
             NBE_SB; MM8(yc, a1w, b1x, 0, nb, px); NBE_SB;                    // W_s.x, correction terms
             LA(a1d, aS1 + 4 * CT);                                           // (the dW_s~ operands follow as registers free up)
-            NBE_SB; MM8(ym, a0, b1x, 2, nb, px); NBE_SB;                     //        main term
+            NBE_SB; MM8(ym, a0, b1x, 2, nb, px, true); NBE_SB;               //        main term
             if (!(a.flags & F_SKIP_NODX)) {                                  // (conv_l00: the input field has no tangent)
                 MM8(dc, a1w, b1d, 4, nb, px); NBE_SB;                        // W_s.dx~
                 LA(a0d, aS0 + 4 * CT);
-                NBE_SB; MM8(dm, a0, b1d, 6, nb, px); NBE_SB;
+                NBE_SB; MM8(dm, a0, b1d, 6, nb, px, true); NBE_SB;
             } else {
                 LA(a0d, aS0 + 4 * CT);
                 if (px) {
@@ -1413,7 +1426,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a0d[mt] = ks ? a0d[mt] : zero;
             NBE_SB; MM8(dc, a1d, b1x, 8, nb, px); NBE_SB;                    // dW_s~.x
-            MM8(dm, a0d, b1x, 10, nb, px); NBE_SB;
+            MM8(dm, a0d, b1x, 10, nb, px, true); NBE_SB;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
@@ -1640,6 +1653,9 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
     auto mm = [&](f32x4& acc, const half8& A, const half8& B) {   // accumulators pinned in AGPRs, updated in place
         asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
     };
+    auto mmz = [&](f32x4& acc, const half8& A, const half8& B) {  // behind a VALU select: see conv_h3q_kernel
+        asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+    };
 
     // ---- operands
     constexpr int A1OFF = SPLIT ? 64 : 128;                      // a1 = a0 + one row (lo part) / two rows (dw set)
@@ -1659,9 +1675,10 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
     };
     // one product on one half tile: 8 MFMAs on tiles t = 8*mt + 4*hf + j; kind 1 / 2: DMA slots `slot`, `slot + 1`
     auto MM8 = [&](f32x4 (&acc)[16], const half8 (&A)[2], const half8 (&B)[4], int hf, int kind, int slot, int g,
-                   int gn, long xo, int nb, bool px) {
+                   int gn, long xo, int nb, bool px, bool zsel = false /* A comes out of a VALU select */) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            if (zsel && (i & 3) == 0) mmz(acc[8 * (i >> 2) + 4 * hf + (i & 3)], A[i >> 2], B[i & 3]); else
             mm(acc[8 * (i >> 2) + 4 * hf + (i & 3)], A[i >> 2], B[i & 3]);
             if (kind != 0 && (i & 3) == 3) {
                 const int k = slot + (i >> 2);
@@ -1739,8 +1756,8 @@ __global__ __launch_bounds__(512, 2) void conv_h2q_kernel(ConvKArgs a) {
             am[0] = ks ? am[0] : zero;                                       // [0 | a0]
             am[1] = ks ? am[1] : zero;
         }
-        NBE_SB; MM8(acc0, am, bsa, 0, 0, 0, g, gn, xo, nb, px); NBE_SB;        // a0.b0
-        MM8(acc0, am, bsb, 1, 0, 0, g, gn, xo, nb, px); NBE_SB;
+        NBE_SB; MM8(acc0, am, bsa, 0, 0, 0, g, gn, xo, nb, px, true); NBE_SB;  // a0.b0
+        MM8(acc0, am, bsb, 1, 0, 0, g, gn, xo, nb, px, true); NBE_SB;
         __syncthreads();                                         // weight buffer B has landed
 
         // ======== second stage: taps (5,6) (7,8) from weight buffer B
@@ -2097,7 +2114,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
     static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
     const bool split = pw.prec == PREC_F16X3;
-    static const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);         // A/B switch, default on
+    const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);   // A/B switch, default on (read per launch: tests flip it)
     if (stem_on && ka.stem_w && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
         !(ka.flags & F_RES) && ka.nskip == 0 && !ka.beta)
         return launch_stem(ka, s);
@@ -2110,7 +2127,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     if (ka.beta) {                                               // gauged input tangent: only conv_h3g_kernel reads it
         if (!(pw.mode == MODE_FLAT3 && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) return 1;   // no gauged kernel
         if (split) {
-            static const bool tall = !(getenv("NBE_H3G_TALL") && atoi(getenv("NBE_H3G_TALL")) == 0);   // A/B switch, default on
+            const bool tall = !(getenv("NBE_H3G_TALL") && atoi(getenv("NBE_H3G_TALL")) == 0);   // A/B switch, default on (read per launch)
             if (pw.cout_t == 16) return launch_h3g<true, false>(ka, ct, s);
             return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
         }

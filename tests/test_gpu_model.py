@@ -116,6 +116,38 @@ def test_gauged_tangent_paths(engine_factory, small, monkeypatch, prec):
     _check(dt, vt, dt_o[0], vt_o[0], "tiny style factor")
 
 
+@pytest.mark.parametrize("switch", ["NBE_H3G_TALL", "NBE_STEM", "NBE_UP8", "NBE_NARROW"])
+def test_kernel_ab_switches_keep_parity(engine_factory, small, monkeypatch, switch):
+    """Every A/B switch of the f16x3 velocity path selects kernels that stay held to the oracle: the 2 x 4 wave tile of
+    conv_h3g_kernel (its zero-select once sat next to an asm MFMA, tests/test_mfma_hazards.py), the general first-layer kernel,
+    eight up-sampling launches, the wide tile for the head."""
+    p, x, d_o, v_o = small
+    monkeypatch.setenv(switch, "0")
+    e = engine_factory(mid_chan=8, compute_vel=True, precision="f16x3")
+    e.load_params(p, premodulated=False)
+    e.set_cosmology(OM, DZ)
+    e.profile_enable(True)
+    d, v = e.forward(x, DZ, VF)
+    e.profile_enable(False)
+    names = [k["kernel"] for k in e.profile_read()]
+    _check(d, v, d_o, v_o, switch + "=0")
+    if switch == "NBE_STEM":
+        assert not any(n.startswith("stem_h3") for n in names)
+    if switch == "NBE_UP8":
+        assert not any(n.startswith("up_h3") for n in names)
+    monkeypatch.delenv(switch)
+    e = engine_factory(mid_chan=8, compute_vel=True, precision="f16x3")     # (the head's tile is wired when the weights load)
+    e.load_params(p, premodulated=False)
+    e.set_cosmology(OM, DZ)
+    e.profile_enable(True)
+    d1, v1 = e.forward(x, DZ, VF)
+    e.profile_enable(False)
+    names = [k["kernel"] for k in e.profile_read()]
+    _check(d1, v1, d_o, v_o, switch + " default")
+    assert any(n.startswith("stem_h3") for n in names) and any(n.startswith("up_h3") for n in names)
+    assert rel_l2(d1, d) <= 2e-6 and rel_l2(v1, v) <= 5e-6
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_premodulated_pairs_are_recognised(engine_factory, small, prec):
     """Premodulated (W, dW) pairs made by modulate_emulator_parameters_vel factorise as dW = W (alpha[ci] + beta[co]); the
