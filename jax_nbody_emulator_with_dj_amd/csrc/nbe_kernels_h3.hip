@@ -1175,25 +1175,33 @@ static int launch_h3q(ConvKArgs ka, int ctiles, hipStream_t s) {
 // pair a wave reads 2 * MT + 4 * NT 16-byte operand sets from LDS: 20 for 2 x 4, 16 for 4 x 2 -- and on this chip, which
 // runs the kernel against its power limit, an LDS operand read costs 0.58 of an MFMA's energy
 // (tools/micro/mfma_power.hip, profiles/r02_mfma_power.txt), so bytes per MFMA are time.
-template <bool NARROW, bool TALL = false>
+// BIG (wide tile only): 256 threads, ONE wave per SIMD with all 512 registers: wave tile 64 couts x two patch rows (4 x 4 MFMA
+// tiles, 256 accumulator registers), 24 operand reads per 96 MFMAs (0.25 per MFMA against 0.33 for 4 x 2).  Same LDS image,
+// same DMA -- issued by four waves instead of eight, four slots per product.
+template <bool NARROW, bool TALL = false, bool BIG = false>
 struct HGGeom {
-    static_assert(!(NARROW && TALL), "the narrow tile has one row of MFMA tiles");
+    static_assert(!(NARROW && TALL) && !(NARROW && BIG) && !(TALL && BIG), "one geometry at a time");
     static constexpr int CT = NARROW ? 16 : 64;             // couts per tile = rows of one weight unit in LDS
     static constexpr int TAPU = 4 * CT;                     // 16-byte units per tap
     static constexpr int WG = 9 * TAPU;                     // units of one group's weights (set w)
     static constexpr int XBASE = 2 * WG;                    // the two patch buffers follow the two weight buffers
     static constexpr int LDS_UNITS = XBASE + 2 * HQ_XB;
-    static constexpr int MT = NARROW ? 1 : (TALL ? 4 : 2), NT = (NARROW || TALL) ? 2 : 4, NTILE = MT * NT;   // MFMA tiles of a wave
+    static constexpr int MT = NARROW ? 1 : ((TALL || BIG) ? 4 : 2), NT = (NARROW || TALL) ? 2 : 4, NTILE = MT * NT;   // MFMA tiles of a wave
+    static constexpr int NW = BIG ? 4 : 8;                  // waves per workgroup
+    static constexpr int XS = 24 / NW;                      // patch DMA slots per wave and tensor (24 wave-instructions per tensor)
+    static constexpr int SPP = NTILE == 16 ? 4 : 2;         // DMA slots a product can carry (one after every fourth MFMA)
     static constexpr bool ROWW = NARROW || TALL;            // a wave owns ONE row of the 8 x 32 patch (else two)
     static constexpr int NWI = WG / 64;                     // weight DMA wave-instructions per group: 36 / 9
-    static constexpr int NWS = (NWI + 7) / 8;               // ... slots per wave: 5 / 2
+    static constexpr int NWS = (NWI + NW - 1) / NW;         // ... slots per wave: 5 / 2 / 9
+    static_assert(NWS + 2 * XS <= 6 * SPP, "the first tap pair carries the whole DMA of the next group");
 };
 static_assert(HGGeom<false>::XBASE == HQ_XBASE, "the two weight buffers fill exactly what conv_h3q_kernel uses for four");
 
-template <bool NARROW, bool TALL>
-__global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
-    typedef HGGeom<NARROW, TALL> G;
+template <bool NARROW, bool TALL, bool BIG>
+__global__ __launch_bounds__(BIG ? 256 : 512, BIG ? 1 : 2) void conv_h3g_kernel(ConvKArgs a) {
+    typedef HGGeom<NARROW, TALL, BIG> G;
     constexpr bool ROWW = G::ROWW;
+    constexpr int NW = G::NW, XS = G::XS, SPP = G::SPP;
     constexpr int CT = G::CT, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = G::MT, NT = G::NT, NTILE = G::NTILE;
     constexpr int NWS = G::NWS;
 #if NBE_DBG   // phases as h3q_stamps: 0 prologue, 1 group up to its barrier, 2 own DMA, 3 barrier, 4 the three products after it, 7 epilogue
@@ -1243,16 +1251,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         nx.x = e.x + to; nx.dx = e.dx + to; nx.psb = e.psb; nx.w0 = e.w + (sk ? wcs : wcm); nx.sk = sk;
     };
     auto dma_w = [&](int buf, int t) {
-        const int n = wave + 8 * t;
+        const int n = wave + NW * t;
         constexpr int PER = TAPU / 64;                           // wave-instructions per skip weight set: 4 / 1
         if (!nx.sk) { if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, lane16, lds + buf * WGU + n * 64); }
         else if (n < 2 * PER) dma16s(nx.w0 + (n < PER ? 0 : a.dws_delta) + (long)(n % PER) * 1024, lane16, lds + buf * WGU + n * 64);
     };
-    unsigned xoff[3];                                            // per-lane byte offset inside a patch plane
-    bool xval[3];
+    unsigned xoff[XS];                                           // per-lane byte offset inside a patch plane
+    bool xval[XS];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int k = (wave + 8 * t) % 6;
+    for (int t = 0; t < XS; ++t) {
+        const int k = (wave + NW * t) % 6;
         const int u = k * 64 + lane;
         xval[t] = u < HP_PL;
         const int uu = xval[t] ? u : HP_PL - 1;
@@ -1260,15 +1268,15 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         xoff[t] = (unsigned)(row * a.W + col) * 16u;
     }
     auto dma_x = [&](int tensor, int t, int buf) {
-        const int n = wave + 8 * t, pl = n / 6, k = n - 6 * pl;
+        const int n = wave + NW * t, pl = n / 6, k = n - 6 * pl;
         if (xval[t])
             dma16s((tensor ? nx.dx : nx.x) + (long)pl * nx.psb, xoff[t],
                    lds + XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HQ_PP + k * 64);
     };
-    auto dma_slot = [&](int k, int buf) {                        // slot k of the NWS + 6 (11 / 8) of the group in `nx`
+    auto dma_slot = [&](int k, int buf) {                        // slot k of the NWS + 2 XS (11 / 8 / 21) of the group in `nx`
         if (k < NWS) dma_w(buf, k);
-        else if (k < NWS + 3) dma_x(0, k - NWS, buf);
-        else if (k < NWS + 6) dma_x(1, k - NWS - 3, buf);
+        else if (k < NWS + XS) dma_x(0, k - NWS, buf);
+        else if (k < NWS + 2 * XS) dma_x(1, k - NWS - XS, buf);
     };
 
     f32x4 ym[NTILE], yc[NTILE], dm[NTILE], dc[NTILE];            // AGPRs, updated in place (see conv_h3q_kernel)
@@ -1285,8 +1293,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
     };
 
-    const int rowc = ROWW ? 0 : 32 * it;                         // first cout row of this wave inside the tile
-    const int rowp = ROWW ? wave : 2 * jq;                       // first patch row of this wave
+    const int rowc = (ROWW || BIG) ? 0 : 32 * it;                // first cout row of this wave inside the tile
+    const int rowp = ROWW ? wave : (BIG ? 2 * wave : 2 * jq);    // first patch row of this wave
     const int aP = (ks * 4 + 2 * kh) * CT + rowc + c;
     const int bB = (2 * kh) * HQ_PP + rowp * HP_RS + c;
     const int bP1 = bB + ks, bP32 = bB + 32 * ks;
@@ -1306,9 +1314,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         for (int t = 0; t < NTILE; ++t) {
             if (zsel && (t % NT) == 0) mmz(acc[t], A[t / NT], B[t % NT]); else
             mm(acc[t], A[t / NT], B[t % NT]);
-            if (slot >= 0 && (NTILE == 8 ? (t % 4) == 3 : t == NTILE - 1)) {
+            if (slot >= 0 && (NTILE >= 8 ? (t % 4) == 3 : t == NTILE - 1)) {
                 if (px) {
-                    if (NTILE == 8) dma_slot(slot + t / 4, nb);
+                    if (NTILE >= 8) dma_slot(slot + t / 4, nb);
                     else { dma_slot(slot, nb); dma_slot(slot + 1, nb); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1324,22 +1332,22 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         LA(wl, wa + CT + aP); LB(dxh, xp + HQ_XT);
         NBE_SB; MM8(yc, wh, xl, slot0, nb, px); NBE_SB;
         LB(dxl, xp + HQ_XT + HQ_PP);
-        NBE_SB; MM8(ym, wh, xh, slot0 < 0 ? -1 : slot0 + 2, nb, px); NBE_SB;
-        MM8(dm, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px); NBE_SB;
+        NBE_SB; MM8(ym, wh, xh, slot0 < 0 ? -1 : slot0 + SPP, nb, px); NBE_SB;
+        MM8(dm, wh, dxh, slot0 < 0 ? -1 : slot0 + 2 * SPP, nb, px); NBE_SB;
         mid();
         preXl();
-        NBE_SB; MM8(dc, wh, dxl, slot0 < 0 ? -1 : slot0 + 6, nb, px); NBE_SB;
+        NBE_SB; MM8(dc, wh, dxl, slot0 < 0 ? -1 : slot0 + 3 * SPP, nb, px); NBE_SB;
         preW();
-        NBE_SB; MM8(yc, wl, xh, slot0 < 0 ? -1 : slot0 + 8, nb, px); NBE_SB;
+        NBE_SB; MM8(yc, wl, xh, slot0 < 0 ? -1 : slot0 + 4 * SPP, nb, px); NBE_SB;
         preXh();
-        NBE_SB; MM8(dc, wl, dxh, slot0 < 0 ? -1 : slot0 + 10, nb, px); NBE_SB;
+        NBE_SB; MM8(dc, wl, dxh, slot0 < 0 ? -1 : slot0 + 5 * SPP, nb, px); NBE_SB;
     };
 
     // ---- prologue: group 0
     {
         set_next(0);
 #pragma unroll
-        for (int k = 0; k < NWS + 6; ++k) dma_slot(k, 0);
+        for (int k = 0; k < NWS + 2 * XS; ++k) dma_slot(k, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         NBE_STAMP(0)
@@ -1411,22 +1419,22 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
             for (int mt = 0; mt < MT; ++mt) a0[mt] = ks ? a0[mt] : zero;
             NBE_SB; MM8(yc, a1w, b1x, 0, nb, px); NBE_SB;                    // W_s.x, correction terms
             LA(a1d, aS1 + 4 * CT);                                           // (the dW_s~ operands follow as registers free up)
-            NBE_SB; MM8(ym, a0, b1x, 2, nb, px, true); NBE_SB;               //        main term
+            NBE_SB; MM8(ym, a0, b1x, SPP, nb, px, true); NBE_SB;             //        main term
             if (!(a.flags & F_SKIP_NODX)) {                                  // (conv_l00: the input field has no tangent)
-                MM8(dc, a1w, b1d, 4, nb, px); NBE_SB;                        // W_s.dx~
+                MM8(dc, a1w, b1d, 2 * SPP, nb, px); NBE_SB;                  // W_s.dx~
                 LA(a0d, aS0 + 4 * CT);
-                NBE_SB; MM8(dm, a0, b1d, 6, nb, px, true); NBE_SB;
+                NBE_SB; MM8(dm, a0, b1d, 3 * SPP, nb, px, true); NBE_SB;
             } else {
                 LA(a0d, aS0 + 4 * CT);
                 if (px) {
 #pragma unroll
-                    for (int k = 4; k < 8; ++k) dma_slot(k, nb);
+                    for (int k = 2 * SPP; k < 4 * SPP; ++k) dma_slot(k, nb);
                 }
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a0d[mt] = ks ? a0d[mt] : zero;
-            NBE_SB; MM8(dc, a1d, b1x, 8, nb, px); NBE_SB;                    // dW_s~.x
-            MM8(dm, a0d, b1x, 10, nb, px, true); NBE_SB;
+            NBE_SB; MM8(dc, a1d, b1x, 4 * SPP, nb, px); NBE_SB;              // dW_s~.x
+            MM8(dm, a0d, b1x, 5 * SPP, nb, px, true); NBE_SB;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
@@ -1448,7 +1456,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
         // (loads first), then the tiles -- all MT rows at once do not fit the registers of the 4 x 2 wave tile
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            int unit = ct * (CT / 8) + (ROWW ? 0 : 4 * it) + 2 * mt + ks;
+            int unit = ct * (CT / 8) + ((ROWW || BIG) ? 0 : 4 * it) + 2 * mt + ks;
             const bool uok = unit < a.cout_groups;
             if (!uok) unit = a.cout_groups - 1;
             const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * kh);
@@ -1519,14 +1527,14 @@ __global__ __launch_bounds__(512, 2) void conv_h3g_kernel(ConvKArgs a) {
 #undef NBE_STAMP
 }
 
-template <bool NARROW, bool TALL>
+template <bool NARROW, bool TALL, bool BIG = false>
 static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
-    typedef HGGeom<NARROW, TALL> G;
+    typedef HGGeom<NARROW, TALL, BIG> G;
     constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_h3g_kernel<NARROW, TALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3g_kernel<NARROW, TALL, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     ka.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
@@ -1551,8 +1559,8 @@ static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
                                (const char*)ka.ws + (long)sc * G::TAPU * 16, ps * 16};
     }
     ka.dws_delta = nskip ? (const char*)ka.dws - (const char*)ka.ws : 0;
-    dim3 grid(ka.ntiles * ctiles, 1, 1), block(512, 1, 1);
-    hipLaunchKernelGGL((conv_h3g_kernel<NARROW, TALL>), grid, block, smem, s, ka);
+    dim3 grid(ka.ntiles * ctiles, 1, 1), block(G::NW * 64, 1, 1);
+    hipLaunchKernelGGL((conv_h3g_kernel<NARROW, TALL, BIG>), grid, block, smem, s, ka);
     return 0;
 }
 
@@ -2129,6 +2137,8 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         if (split) {
             const bool tall = !(getenv("NBE_H3G_TALL") && atoi(getenv("NBE_H3G_TALL")) == 0);   // A/B switch, default on (read per launch)
             if (pw.cout_t == 16) return launch_h3g<true, false>(ka, ct, s);
+            const bool big = getenv("NBE_H3G_BIG") && atoi(getenv("NBE_H3G_BIG")) == 1;   // A/B switch: 4 x 4 wave tile, one wave per SIMD
+            if (big) return launch_h3g<false, false, true>(ka, ct, s);
             return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
         }
         return launch_h2q<false, true>(ka, ct, s);
