@@ -214,6 +214,12 @@ double nbe_vel_norm(double z, double Om);
 int nbe_test_layer(nbe_ctx* ctx, int kind, int crop, int flags, const float* x, const float* dx, int cin,
                    int D, int H, int W, const float* w, const float* dw, const float* bias, int cout,
                    const float* res, const float* dres, float* y, float* dy);
+/* The gauged form of a 3x3x3 layer (style_layers_vel.py:98-105 with dW = W (.) (alpha[ci] + beta[co])):
+ * dx is the input tangent in this layer's gauge, y = W.x + b, dy = W.dx + beta[o] * (W.x); flags: 1 = LeakyReLU.
+ * f16x3 contexts run conv_h3w_kernel (Winograd F(2,3) along z) when the output has an even number of planes, Cin <= 128
+ * and NBE_WINO is not 0, else conv_h3g_kernel. */
+int nbe_test_layer_gauged(nbe_ctx* ctx, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
+                          const float* w, const float* beta, const float* bias, int cout, float* y, float* dy);
 /* modulation kernel alone: OIDHW weight -> (w_n, dw_tot) */
 int nbe_test_modulate(nbe_ctx* ctx, const float* weight, const float* style_weight, const float* style_bias,
                       int cout, int cin, int k, float s0, float s1, float eps, int first_layer,

@@ -136,6 +136,9 @@ struct nbe_ctx {
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
     bool fuse = false;                            // ... and the blocks' skips run fused into their conv_1 (f16x3 only)
     int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
+    // Winograd-z form of the gauged 3x3x3 layers (conv_h3w_kernel): packed beside pw.w for every gauged wide layer;
+    // wino_ok is cleared when a weight of the current modulation leaves the f16 range at the kernel's 2^14 scale
+    int* wino_flag = nullptr; bool wino_ok = false;
     // Range shift of the f16-based arithmetic (include/nbe.h, "Range"): activations and biases of a call are multiplied
     // by act_scale = 2^k (exact), the head divides it out.  flags[0]: bit pattern of max |input| (launch_absmax),
     // flags[1]: a non-finite value was written by the head.
@@ -413,9 +416,13 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
         cl.bias = L.bias_f;
     }
     const PackedW& pw = (g6 && L.kind == 0 && narrow_tile(&L)) ? L.pwn : L.pw;
+    // Winograd along z (conv_h3w_kernel): gauged wide 3x3x3 launches without a fused skip or residual, on an even number
+    // of output planes (the conditions of launch_h3w).  NBE_WINO=0 is the A/B switch (read per launch: tests flip it).
+    cl.wino = g6 && c->wino_ok && &pw == &L.pw && pw.ww && !cl.skw && !(cl.flags & F_RES) && (cl.Dv & 1) == 0 && cl.in_off == 0 &&
+              cl.osz == 1 && !(getenv("NBE_WINO") && atoi(getenv("NBE_WINO")) == 0);
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
-        pe = prof_entry(c, conv_name(pw, c->vel, has_dx, g6, cl.set < 0));
+        pe = prof_entry(c, cl.wino ? std::string("conv_h3w<FLAT3,vel,dx>") : conv_name(pw, c->vel, has_dx, g6, cl.set < 0));
         ea = get_event(c); eb = get_event(c);
         (void)hipEventRecord(ea, c->stream);
     }
@@ -1187,7 +1194,7 @@ static void free_layers(nbe_ctx* c) {
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
-        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pw.stem); (void)hipFree(L.pwn.w); (void)hipFree(L.pwn.dw); (void)hipFree(L.bias_f);
+        (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pw.stem); (void)hipFree(L.pw.ww); (void)hipFree(L.pwn.w); (void)hipFree(L.pwn.dw); (void)hipFree(L.bias_f);
         (void)hipFree(L.alpha); (void)hipFree(L.beta);
     }
     c->layers.clear();
@@ -1223,6 +1230,23 @@ static int expected_shape(nbe_ctx* c, const std::string& blk, const std::string&
 
 static const char* kBlocks[15] = {"conv_l00", "conv_l01", "down_l0", "conv_l1", "down_l1", "conv_l2", "down_l2", "conv_c",
                                   "up_r2", "conv_r2", "up_r1", "conv_r1", "up_r0", "conv_r00", "conv_r01"};
+
+// Winograd-z weights of the gauged wide 3x3x3 layers (conv_h3w_kernel), from the modulated weights L.wn that are current
+static int pack_wino(nbe_ctx* c) {
+    c->wino_ok = false;
+    if (!(c->gauge_active && c->prec == PREC_F16X3 && c->vel)) return 0;
+    if (!c->wino_flag) HIPCHK(hipMalloc((void**)&c->wino_flag, 4));
+    HIPCHK(hipMemsetAsync(c->wino_flag, 0, 4, c->stream));
+    for (auto& kv : c->layers) {
+        Layer& L = kv.second;
+        if (L.pw.ww && L.g6) launch_pack_h3w(L.wn, L.cout, L.cin, L.pw.cin_pad, L.pw.ctiles, L.pw.ww, c->wino_flag, c->stream);
+    }
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, c->wino_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->wino_ok = bad == 0;
+    return 0;
+}
 
 // Tangent gauges of the style path (conv_h3g_kernel): every tensor with a tangent stores dx + a (.) x, a = the alpha
 // of the one 3x3x3 layer that reads it, so that layer runs two products instead of three; the tensor's other readers
@@ -1382,7 +1406,7 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
     HIPCHK(hipStreamSynchronize(c->stream));
     c->gauge_active = c->gauge;
     c->fuse = c->gauge && c->prec == PREC_F16X3;
-    return 0;
+    return pack_wino(c);
 }
 
 static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool style) {
@@ -1426,6 +1450,9 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             HIPCHK(hipMalloc((void**)&pn.w, pn.floats * 4));
             if (L.kind == 1) HIPCHK(hipMalloc((void**)&pn.dw, pn.floats * 4));   // a skip that runs inside the narrow conv_1
         }
+        // Winograd-z packing (conv_h3w_kernel): 4 transformed kernels per 3 dz slices, wide tile only, Cin <= 128
+        if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && !L.first && !L.pwn.w && pw.cin_pad / 16 <= 8)
+            HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
         // the first layer in its own packing (stem_h3_kernel): K = 27 taps x 3 channels = 81 <= 96
         if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && L.first && d.cin <= 3 && d.cout <= 64)
             HIPCHK(hipMalloc((void**)&pw.stem, 4 * 3 * 4 * 64 * 16));
@@ -1505,7 +1532,7 @@ int nbe_destroy(nbe_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     free_layers(c);
-    (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag); (void)hipFree(c->flags);
+    (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag); (void)hipFree(c->wino_flag); (void)hipFree(c->flags);
     drop_graphs(c);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
     if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
@@ -1596,6 +1623,7 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
     }
     c->gauge_active = use_gauge;
     c->fuse = use_gauge && c->prec == PREC_F16X3;               // blocks with Layer::fskip run their skip inside conv_1
+    if (pack_wino(c)) return 1;
     HIPCHK(hipGetLastError());
     c->modulated = true; c->mod_Om = Om; c->mod_Dz = Dz;
     ++c->epoch;                                                  // captured graphs hold the schedule of the previous modulation
@@ -2142,14 +2170,19 @@ int nbe_test_modulate(nbe_ctx* c, const float* weight, const float* sw, const fl
     return 0;
 }
 
-int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
-                   const float* w, const float* dw, const float* bias, int cout, const float* res, const float* dres,
-                   float* y, float* dy) {
+}  // extern "C"
+
+// beta != NULL: the gauged form of a 3x3x3 layer (conv_h3g_kernel / conv_h3w_kernel / their float32 and float16 siblings):
+// dx is the tangent in this layer's gauge, dy = W.dx + beta[o] * (W.x); dw is not used
+static int test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
+                      const float* w, const float* dw, const float* bias, int cout, const float* res, const float* dres,
+                      float* y, float* dy, const float* beta) {
     if (!c || !x || !w || !bias || !y) return fail("null argument");
     if (kind < 0 || kind > 3) return fail("kind must be 0..3");
+    if (beta && !(kind == 0 && dx && dy)) return fail("the gauged form belongs to 3x3x3 layers with an input tangent");
     HIPCHK(hipSetDevice(c->device));
-    const bool vel = dw != nullptr && dy != nullptr, has_dx = vel && dx != nullptr;
-    const bool saved_vel = c->vel;
+    const bool vel = (dw != nullptr || beta != nullptr) && dy != nullptr, has_dx = vel && dx != nullptr;
+    const bool saved_vel = c->vel, saved_ga = c->gauge_active, saved_wino = c->wino_ok;
     c->vel = vel;
     const int k = kind == 0 ? 3 : kind == 1 ? 1 : 2;
     int OD, OH, OW;
@@ -2182,8 +2215,24 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         TCHK(hipMemcpy(pw.bias, bias, cout * 4, hipMemcpyHostToDevice));
         TCHK(hipMalloc((void**)&dwt, nw * 4)); TCHK(hipMemcpy(dwt, w, nw * 4, hipMemcpyHostToDevice));
         launch_pack(dwt, cout, cin, kind, pw, pw.w, c->stream);
-        if (vel) { TCHK(hipMalloc((void**)&ddw, nw * 4)); TCHK(hipMemcpy(ddw, dw, nw * 4, hipMemcpyHostToDevice));
-                   launch_pack(ddw, cout, cin, kind, pw, pw.dw, c->stream); }
+        if (vel && !beta) { TCHK(hipMalloc((void**)&ddw, nw * 4)); TCHK(hipMemcpy(ddw, dw, nw * 4, hipMemcpyHostToDevice));
+                            launch_pack(ddw, cout, cin, kind, pw, pw.dw, c->stream); }
+        if (beta) {
+            const size_t nbt = (size_t)pw.ctiles * 32 * pw.ni + 64;
+            TCHK(hipMalloc((void**)&L.beta, nbt * 4)); TCHK(hipMemset(L.beta, 0, nbt * 4));
+            TCHK(hipMemcpy(L.beta, beta, cout * 4, hipMemcpyHostToDevice));
+            L.g6 = true; c->gauge_active = true; c->wino_ok = false;
+            if (c->prec == PREC_F16X3 && pw.cin_pad / 16 <= 8) {
+                TCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
+                if (!c->wino_flag) TCHK(hipMalloc((void**)&c->wino_flag, 4));
+                TCHK(hipMemsetAsync(c->wino_flag, 0, 4, c->stream));
+                launch_pack_h3w(dwt, cout, cin, pw.cin_pad, pw.ctiles, pw.ww, c->wino_flag, c->stream);
+                int bad = 0;
+                TCHK(hipMemcpyAsync(&bad, c->wino_flag, 4, hipMemcpyDeviceToHost, c->stream));
+                TCHK(hipStreamSynchronize(c->stream));
+                c->wino_ok = bad == 0;
+            }
+        }
         TCHK(hipMalloc((void**)&dxin, nin * 4)); TCHK(hipMemcpy(dxin, x, nin * 4, hipMemcpyHostToDevice));
         if (has_dx) { TCHK(hipMalloc((void**)&ddx, nin * 4)); TCHK(hipMemcpy(ddx, dx, nin * 4, hipMemcpyHostToDevice)); }
         TCHK(hipMalloc((void**)&dout, nout * 4));
@@ -2249,10 +2298,24 @@ int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, co
         TCHK(hipGetLastError());
 #undef TCHK
     } while (0);
-    c->vel = saved_vel;
+    c->vel = saved_vel; c->gauge_active = saved_ga; c->wino_ok = saved_wino;
     (void)hipFree(dxin); (void)hipFree(ddx); (void)hipFree(dwt); (void)hipFree(ddw); (void)hipFree(dout); (void)hipFree(ws);
-    (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.pw.stem);
+    (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.pw.stem); (void)hipFree(L.pw.ww); (void)hipFree(L.beta);
     return rc;
+}
+
+extern "C" {
+
+int nbe_test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
+                   const float* w, const float* dw, const float* bias, int cout, const float* res, const float* dres,
+                   float* y, float* dy) {
+    return test_layer(c, kind, crop, flags, x, dx, cin, D, H, W, w, dw, bias, cout, res, dres, y, dy, nullptr);
+}
+
+int nbe_test_layer_gauged(nbe_ctx* c, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
+                          const float* w, const float* beta, const float* bias, int cout, float* y, float* dy) {
+    if (!beta) return fail("null argument");
+    return test_layer(c, 0, 0, flags, x, dx, cin, D, H, W, w, nullptr, bias, cout, nullptr, nullptr, y, dy, beta);
 }
 
 int nbe_profile_enable(nbe_ctx* c, int on) { if (!c) return fail("null context"); prof_collect(c); c->prof = on != 0; return 0; }

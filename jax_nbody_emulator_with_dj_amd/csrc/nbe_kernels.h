@@ -61,6 +61,7 @@ struct PackedW {
     int ctiles = 0;          // cout tiles
     int64_t floats = 0;      // size of w (and dw) in floats, per parity set
     int nsets = 1;           // 8 for the up-sample layer (one set per output parity)
+    float* ww = nullptr;     // f16x3 + velocity, gauged 3x3x3 layers on the wide tile: Winograd-z packing of w (conv_h3w_kernel), or NULL
     float* stem = nullptr;   // f16x3 + velocity, conv_l00/conv_0 only: [W hi | W lo | dW hi | dW lo] x 96 k x 64 couts (stem_h3_kernel)
 };
 
@@ -84,6 +85,7 @@ struct ConvLaunch {
     int sk_split_ch = 0;
     int64_t sk_off = 0;            // flat offset in sk of the voxel aligned with output (0, 0, 0)
     const PackedW* skw = nullptr;  // the skip layer's packed weights (FLAT1): w = W_s, dw = dW_s~
+    bool wino = false;             // run the Winograd-z kernel when the layer and the launch have that form (run_conv)
 };
 
 // 0 on success; 1 = the layer / flag combination has no kernel (an engine bug, reported through nbe_last_error)
@@ -100,6 +102,10 @@ void launch_style_alpha(const float* style_weight, const float* style_bias, int 
                         float* alpha, int* flag, hipStream_t s);
 // OIDHW -> packed layout; `kind`: 0 conv3, 1 skip(1x1x1), 2 down(k2 s2), 3 up(k2, 8 parity sets)
 void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s);
+
+// Winograd-z packing of a 3x3x3 layer's modulated weights for conv_h3w_kernel (nbe_kernels_wino.h): dst holds 4/3 of
+// PackedW::floats; *flag |= 1 when a weight leaves the f16 range at the kernel's 2^14 scale
+void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int ctiles, float* dst, int* flag, hipStream_t s);
 
 // data movement --------------------------------------------------------------
 // periodic crop of a (C, Db, Hb, Wb) float box into input planes, scaled by `scale`

@@ -1564,6 +1564,8 @@ static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
     return 0;
 }
 
+#include "nbe_kernels_wino.h"
+
 // ------------------------------------------------------------------------------------------------
 // The two-accumulator variants on the 16x16x32 shape: f16x3 without velocity and plain f16 with velocity
 // ------------------------------------------------------------------------------------------------
@@ -2139,6 +2141,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
             if (pw.cout_t == 16) return launch_h3g<true, false>(ka, ct, s);
             const bool big = getenv("NBE_H3G_BIG") && atoi(getenv("NBE_H3G_BIG")) == 1;   // A/B switch: 4 x 4 wave tile, one wave per SIMD
             if (big) return launch_h3g<false, false, true>(ka, ct, s);
+            if (ka.ww && launch_h3w(ka, ka.ww, ct, s) == 0) return 0;     // Winograd along z; 1: no such form for this launch
             return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
         }
         return launch_h2q<false, true>(ka, ct, s);

@@ -1,0 +1,433 @@
+// Included by nbe_kernels_h3.hip (uses its HGGeom / dma16s / acc_read / patch constants).
+//
+// conv_h3w_kernel: the gauged 3x3x3 layer (conv_h3g_kernel, wide tile) with a Winograd F(2,3) transform ALONG Z.
+//
+// Two output planes z0, z0 + 1 at the same (y, x) come from four input planes d0..d3 = z0..z0 + 3 with four plane-wise
+// 2-D convolutions (nine (dy, dx) taps each) instead of six:
+//     M0 = U0 * (d0 - d2)   M1 = U1 * (d1 + d2)   M2 = U2 * (d2 - d1)   M3 = U3 * (d1 - d3)
+//     U0 = w[dz=0]   U1 = (w0 + w1 + w2) / 2   U2 = (w0 - w1 + w2) / 2   U3 = w[dz=2]
+//     y(z0) = M0 + M1 + M2          y(z0 + 1) = M1 - M2 - M3
+// (Lavin & Gray's F(2,3), applied to the plane index only: the transform matrices have entries 0, +-1, +-1/2, and the
+// one-dimensional form amplifies rounding by < 2: tests hold the kernel to the tolerances of the direct one.)
+// That is 2/3 of the MFMAs of conv_h3g_kernel -- on a chip that runs this loop against its power limit, 2/3 of the time
+// the MFMAs cost.  What makes it fit:
+//
+// * Accumulators.  M1 and M2 enter both planes, so a naive form needs four accumulator sets per plane pair where the
+//   direct kernel has two.  Ordering K removes that: phase 1 runs xi = 1 into set A and xi = 2 into set B over all input
+//   chunks, then (A, B) := (A + B, A - B) in registers, then phase 2 adds xi = 0 to A and xi = 3 (with U3 negated by the
+//   packer) to B: A ends as plane z0, B as plane z0 + 1 -- two sets for two planes, as before.
+// * One accumulator per output instead of a (main, correction) pair: the weights are scaled by 2^14 (style-modulated
+//   weights are unit vectors per cout, so |U| <= 1) and their lo part is kept UNSCALED (|lo| <= 2^3, exact to 2^-24 of
+//   the largest weight); the product hi(w) * lo(x), which the direct kernel sums in a separate accumulator because lo(x)
+//   is stored times 2^11, takes its 2^-11 on the weight operand (one v_pk_mul_f16 per register, exact for every weight
+//   within 2^-18 of the row's scale, absolute error 2^-25 below that).  All three products of a float32 product then
+//   land in the same float32 accumulator; the epilogue multiplies by 2^-14.
+//   => 128 accumulator registers hold 64 couts x 32 positions x 2 planes x (y, dy): the wave tile, LDS image and operand
+//   reads per MFMA of conv_h3g_kernel<false, TALL>.
+// * The transformed planes V = a +- b are built by the workgroup itself: each wave loads its share of the two raw
+//   patches into registers (16 B per lane and part), joins hi/lo to float32, adds, splits again and writes the result
+//   into the LDS patch buffer of the NEXT stage in the layout the B operands are read in.  Weights still arrive by
+//   global -> LDS DMA.  LDS: 2 x 36 KB of weights + 2 x 44 KB of patches, as in conv_h3g_kernel.
+//
+// A stage is (phase, chunk, xi); stage s accumulates into set s & 1.  Per 16 input channels and 512 outputs: 4 stages of
+// 28 MFMAs per tile where the direct kernel runs 6.
+
+constexpr int NBE_MAX_WSTAGES = 32;                // 4 * Cin / 16: Cin <= 128
+constexpr float WINO_WSCALE = 16384.0f;            // 2^14
+
+struct WinoSrc { const char* xa; const char* xb; long dxd; const char* w; long psb; float sb; int pad_; };
+
+struct WinoKArgs {
+    int H, W, Dv, Hv, Wv, Ho, Wo;
+    int nchunk, cout_groups, flags, ntiles, tny, tnx;
+    float* y; float* dy; long out_pstride; int out_g0;
+    const float* bias; const float* gout; const float* beta;
+    float inv_scale;
+    WinoSrc st[NBE_MAX_WSTAGES];
+};
+
+__global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
+    typedef HGGeom<false, true, false> G;
+    constexpr int NW = 8, CT = 64, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = 4, NT = 2, NTILE = 8;
+    f32x4* lds = lds_h3;
+    const half8* L8 = (const half8*)lds_h3;
+    half8* L8w = (half8*)lds_h3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
+
+    const int nct = (a.cout_groups + 7) / 8;
+    const int vt = xcd_tile(blockIdx.x, a.ntiles * nct);
+    const int tile = vt / nct, ct = vt - tile * nct;
+    const int npair = a.Dv >> 1;
+    const int zp = tile % npair, tyx = tile / npair;
+    const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
+    const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS, z0 = 2 * zp;
+    const int nst = 4 * a.nchunk;
+
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const long to = (((long)z0 * a.H + y0) * a.W + x0) * 16;
+    const long wcm = (long)ct * nst * WGU * 16;
+
+    // ---- sources of the stage being prepared
+    struct Nxt { const char *xa, *xb, *w0; long dxd, psb; float sb; } nx;
+    auto set_next = [&](int s) {
+        const WinoSrc e = a.st[s];
+        nx.xa = e.xa + to; nx.xb = e.xb + to; nx.dxd = e.dxd; nx.psb = e.psb; nx.w0 = e.w + wcm; nx.sb = e.sb;
+    };
+    auto dma_w = [&](int buf, int t) {                           // 36 wave-instructions of weights, 5 slots per wave
+        const int n = wave + NW * t;
+        if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, lane16, lds + buf * WGU + n * 64);
+    };
+    // ---- the transformed patch of the next stage: 24 wave-items (tensor, channel half, 64 units of the 340) of a hi and a
+    // lo plane each, three per wave; an item is four 16-byte loads per lane (a hi, a lo, b hi, b lo), 8 channels of
+    // V = a + sb * b in float32, and two 16-byte LDS stores.
+    // (per-lane offsets are recomputed at every use -- a dozen VALU operations per item -- instead of held in registers)
+    auto item_unit = [&](int j, bool& valid) {                   // unit 0..339 of the 10 x 34 patch plane this lane handles in item j
+        int l = lane;
+        asm volatile("" : "+v"(l));                              // (or the compiler hoists the offsets out of the loop and spills them)
+        const int u = ((wave + NW * j) % 6) * 64 + l;
+        valid = u < HP_PL;
+        return valid ? u : HP_PL - 1;
+    };
+    auto item_goff = [&](int uu) {                               // byte offset of that unit in an input plane
+        const int row = (uu * 241) >> 13, col = uu - row * HP_RS;   // uu / 34 for uu < 384
+        return (unsigned)(row * a.W + col) * 16u;
+    };
+    half8 sah, sal, sbh, sbl;
+    float ssb = 0.f;
+    auto st_load = [&](int j) {
+#ifdef WX_NOST
+        return;
+#endif
+        const int n = wave + NW * j;
+        const long po = ((n / 12) ? nx.dxd : 0) + (long)(((n % 12) / 6) * 2) * nx.psb;
+        const char* pa = nx.xa + po;
+        const char* pb = nx.xb + po;
+        // wave-uniform base in SGPRs + 32-bit lane offset (the compiler's own form keeps a 64-bit address per lane and load);
+        // asm loads are invisible to the compiler's vmcnt bookkeeping: st_store waits for them itself
+        bool valid;
+        const unsigned go = item_goff(item_unit(j, valid));
+        auto ld = [&](half8& d, const char* base) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(go), "s"(base) : "memory");
+        };
+        ld(sah, pa); ld(sal, pa + nx.psb); ld(sbh, pb); ld(sbl, pb + nx.psb);
+        ssb = nx.sb;
+    };
+    auto st_store = [&](int j, int buf) {
+#ifdef WX_NOST
+        return;
+#endif
+        half8 hi, lo;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sah), "+v"(sal), "+v"(sbh), "+v"(sbl));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float va = (float)sah[e] + (float)sal[e] * H3_INV;
+            const float vb = (float)sbh[e] + (float)sbl[e] * H3_INV;
+            const float v = va + ssb * vb;
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)((v - (float)hi[e]) * H3_SCALE);
+            if (e == 3) __builtin_amdgcn_sched_barrier(0);       // four channels at a time: half the temporaries
+        }
+        bool valid;
+        const int n = wave + NW * j;
+        const int lo_ = XBASE + buf * HQ_XB + (n / 12) * HQ_XT + (((n % 12) / 6) * 2) * HQ_PP + item_unit(j, valid);
+        if (valid) {
+            L8w[lo_] = hi;
+            L8w[lo_ + HQ_PP] = lo;
+        }
+    };
+
+    f32x4 YA[NTILE], DA[NTILE], YB[NTILE], DB[NTILE];            // AGPRs, updated in place (see conv_h3q_kernel)
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { YA[t][e] = 0.f; DA[t][e] = 0.f; YB[t][e] = 0.f; DB[t][e] = 0.f; }
+    auto mm = [&](f32x4& acc, const half8& A, const half8& B) {
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+    };
+    // behind a VALU write of A: the two wait states the ISA asks for travel with the MFMA (tools/check_mfma_hazards.py)
+    auto mmz = [&](f32x4& acc, const half8& A, const half8& B) {
+        asm("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+    };
+
+    const int rowp = wave;                                       // this wave's row of the 8 x 32 patch
+    const int aP = (ks * 4 + 2 * kh) * CT + c;
+    const int bB = (2 * kh) * HQ_PP + rowp * HP_RS + c;
+    const int bP1 = bB + ks, bP32 = bB + 32 * ks;
+    auto LA = [&](half8 (&r)[MT], int idx) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) r[mt] = L8[idx + 16 * mt];
+    };
+    auto LB = [&](half8 (&r)[NT], int idx) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) r[nt] = L8[idx + 16 * nt];
+    };
+    const _Float16 kInv = (_Float16)H3_INV;
+    // one product on the wave tile; slot >= 0: weight-DMA slots `slot`, `slot + 1` after the two halves of the product
+    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px, bool zsel = false,
+                   bool sc = false /* A times 2^-11, one row of tiles at a time */) {
+        half8 as;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            if (sc) {
+                if ((t % NT) == 0) { as = A[t / NT] * kInv; mmz(acc[t], as, B[t % NT]); } else mm(acc[t], as, B[t % NT]);
+            } else
+            if (zsel && (t % NT) == 0) mmz(acc[t], A[t / NT], B[t % NT]); else
+            mm(acc[t], A[t / NT], B[t % NT]);
+            if (slot >= 0 && (t % 4) == 3) {
+                if (px) dma_w(nb, slot + t / 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#define NBE_SB __builtin_amdgcn_sched_barrier(0)
+    half8 wh[MT], wl[MT], xh[NT], xl[NT], dxh[NT], dxl[NT];
+    // A tap pair: six products into (Y, DY).  On entry wh, xl and xh of the pair are loaded (or in flight); preXl / preW /
+    // preXh request those of whatever follows as soon as the registers are free.  Dependent MFMAs are >= 8 MFMAs apart.
+    // (mid: after the third product every LDS read of the pair has been issued -- the stage's barrier goes there)
+    auto pair = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int slot0, int nb, bool px, int wa, int xp,
+                    auto&& preXl, auto&& preW, auto&& preXh, auto&& mid) {
+        LB(dxh, xp + HQ_XT);
+        NBE_SB; MM8(Y, wh, xl, slot0, nb, px, false, true); NBE_SB;                       // hi(w) 2^-11 . lo(x)
+        LB(dxl, xp + HQ_XT + HQ_PP);
+        NBE_SB; MM8(Y, wh, xh, slot0 < 0 ? -1 : slot0 + 2, nb, px); NBE_SB;               // hi . hi
+        LA(wl, wa + CT + aP);
+        NBE_SB; MM8(DY, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px); NBE_SB;
+        mid();
+        preXl();
+        NBE_SB; MM8(DY, wh, dxl, -1, nb, px, false, true); NBE_SB;
+        preW();
+        NBE_SB; MM8(Y, wl, xh, -1, nb, px); NBE_SB;                                       // lo(w) . hi(x)
+        preXh();
+        NBE_SB; MM8(DY, wl, dxh, -1, nb, px); NBE_SB;
+    };
+
+    constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
+    auto stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s) {
+        const bool px = s + 1 < nst;
+        if (px) set_next(s + 1);
+        // (the buffer parity is a compile-time constant of each instantiation: hidden from the compiler, which would
+        // otherwise precompute one address register per LDS read of the stage -- dozens, spilled)
+        int par = s & 1;
+        asm volatile("" : "+s"(par));
+        const int nb = 1 - par;
+        const int wb = par * WGU, xb = XBASE + par * HQ_XB;
+        const int wbn = WGU - wb, xbn = XBASE + nb * HQ_XB;
+        if (px) st_load(0);
+        pair(Y, DY, 0, nb, px, wb, xb + bP1,                                              // taps (0,1) + the weight DMA of stage s+1
+             [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
+             [&] {});
+        if (px) { st_store(0, nb); st_load(1); }
+        half8 a1[MT], a2[MT], b1x[NT], b1d[NT];
+        // single tap 4 = (dy 1, dx 1): the K halves select the PART: [wh | wh 2^-11] . [xh | xl] and [wl | 0] . [xh | xl]
+        const int aS = wb + 4 * TAPU + (2 * kh) * CT + c;
+        const int bS = xb + (2 * kh + ks) * HQ_PP + rowp * HP_RS + c + SH4;
+        pair(Y, DY, -1, nb, px, wb + 2 * TAPU, xb + 2 + bP32,                             // taps (2,3)
+             [&] { LB(b1x, bS); }, [&] { LA(a1, aS); LA(a2, aS + CT); }, [&] { LB(b1d, bS + HQ_XT); }, [&] {});
+        {
+            const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            const _Float16 m1 = ks ? kInv : (_Float16)1.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { a1[mt] = a1[mt] * m1; a2[mt] = ks ? zero : a2[mt]; }
+        }
+        NBE_SB; MM8(Y, a1, b1x, -1, 0, false, true); NBE_SB;
+        LB(xl, xb + SH5 + bP32 + HQ_PP);
+        NBE_SB; MM8(DY, a1, b1d, -1, 0, false); NBE_SB;
+        LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
+        NBE_SB; MM8(Y, a2, b1x, -1, 0, false, true); NBE_SB;
+        MM8(DY, a2, b1d, -1, 0, false); NBE_SB;
+        if (px) { st_store(1, nb); st_load(2); }
+        pair(Y, DY, -1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                           // taps (5,6)
+             [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
+             [&] {});
+        if (px) st_store(2, nb);
+        // taps (7,8); the stage's one barrier sits after the third product: by then this wave has read everything it
+        // needs from the buffers of stage s, and the patch and weights of stage s+1 are complete once every wave has
+        // waited for its own stores and DMA
+        pair(Y, DY, -1, nb, px, wb + 7 * TAPU, xb + SH7 + bP1,
+             [&] { if (px) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (px) LA(wh, wbn + aP); }, [&] { if (px) LB(xh, xbn + bP1); },
+             [&] { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); });
+    };
+
+    // ---- prologue: stage 0
+    {
+        set_next(0);
+#pragma unroll
+        for (int k = 0; k < G::NWS; ++k) dma_w(0, k);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { st_load(j); st_store(j, 0); }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        LA(wh, aP); LB(xl, XBASE + bP1 + HQ_PP); LB(xh, XBASE + bP1);
+    }
+
+    for (int s2 = 0; s2 < 2 * a.nchunk; ++s2) {
+#ifndef WX_NOBF
+        if (s2 == a.nchunk) {
+            // end of phase 1: A = M1, B = M2  ->  A = M1 + M2, B = M1 - M2
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA results -> accumulator reads
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+                // one tile at a time, and back in its accumulator registers before the next one is touched
+                f32x4 p, m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { p[e] = acc_read(YA[t][e]); m[e] = acc_read(YB[t][e]); }
+                YA[t] = p + m; YB[t] = p - m;
+                asm volatile("" : "+a"(YA[t]), "+a"(YB[t]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { p[e] = acc_read(DA[t][e]); m[e] = acc_read(DB[t][e]); }
+                DA[t] = p + m; DB[t] = p - m;
+                asm volatile("" : "+a"(DA[t]), "+a"(DB[t]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_nop 7" ::: "memory");                 // accumulator writes -> the next MFMAs' C operands
+        }
+#endif
+        stage(YA, DA, 2 * s2);
+        stage(YB, DB, 2 * s2 + 1);
+    }
+#undef NBE_SB
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
+
+    // ---- epilogue: y = W.x / 2^14 + b, dy = W.dx~ / 2^14 + beta * (W.x), LeakyReLU (+ tangent), gauge, split, store
+    auto epilogue = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int z) {
+        const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
+        int o[NT];
+        bool ook[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int yy = y0 + rowp, xx = x0 + 16 * nt + c;
+            ook[nt] = yy < a.Hv && xx < a.Wv;
+            o[nt] = ook[nt] ? (z * a.Ho + yy) * a.Wo + xx : z * a.Ho * a.Wo;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int unit = ct * (CT / 8) + 2 * mt + ks;
+            const bool uok = unit < a.cout_groups;
+            if (!uok) unit = a.cout_groups - 1;
+            const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * kh);
+            const f32x4 be = *(const f32x4*)(a.beta + unit * 8 + 4 * kh);
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+            if (gauge) gv = *(const f32x4*)(a.gout + unit * 8 + 4 * kh);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int t = mt * NT + nt;
+                f32x4 v, dv;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yp = acc_read(Y[t][e]) * a.inv_scale;
+                    v[e] = yp + bv[e];
+                    dv[e] = acc_read(DY[t][e]) * a.inv_scale + be[e] * yp;
+                }
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
+                        v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                    }
+                }
+                if (gauge) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[e] += gv[e] * v[e];
+                }
+                if (uok && ook[nt]) {
+                    const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
+                    const long ol = ob + a.out_pstride * 16;
+                    half4 hi, lo;
+                    split4(v, hi, lo);
+                    *(half4*)((char*)a.y + ob) = hi;
+                    *(half4*)((char*)a.y + ol) = lo;
+                    split4(dv, hi, lo);
+                    *(half4*)((char*)a.dy + ob) = hi;
+                    *(half4*)((char*)a.dy + ol) = lo;
+                }
+            }
+        }
+    };
+    epilogue(YA, DA, z0);
+    epilogue(YB, DB, z0 + 1);
+}
+
+// Winograd packing of a 3x3x3 layer's weights (OIDHW float32) for conv_h3w_kernel:
+// [ct][stage = chunk*4 + xi][tap = 3*dy + dx][u = 2*h + part][co 64][j 8], channel = chunk*16 + 8*h + j;
+// value = U_xi[oc, ci, dy, dx] * 2^14 (U3 negated), part 0 = its f16 rounding, part 1 = the remainder, unscaled.
+// *flag |= 1 when a scaled weight leaves the f16 range (the layer then stays on the direct kernel).
+__global__ __launch_bounds__(256) void pack_h3w_kernel(const float* __restrict__ w, int cout, int cin, int nchunk, long total,
+                                                       _Float16* __restrict__ dst, int* __restrict__ flag) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    long r = idx;
+    const int j = (int)(r % 8); r /= 8;
+    const int co = (int)(r % 64); r /= 64;
+    const int u = (int)(r % 4); r /= 4;
+    const int tap = (int)(r % 9); r /= 9;
+    const int stage = (int)(r % (4 * nchunk)); r /= 4 * nchunk;
+    const int ct = (int)r;
+    const int chunk = stage >> 2, xi = stage & 3;
+    const int h = u >> 1, part = u & 1;
+    const int ci = chunk * 16 + 8 * h + j, oc = ct * 64 + co;
+    float v = 0.f;
+    if (oc < cout && ci < cin) {
+        const float* p = w + (((size_t)oc * cin + ci) * 3) * 9 + tap;        // [dz][dy][dx]
+        const float w0 = p[0], w1 = p[9], w2 = p[18];
+        v = xi == 0 ? w0 : xi == 1 ? 0.5f * (w0 + w1 + w2) : xi == 2 ? 0.5f * (w0 - w1 + w2) : -w2;
+    }
+    v *= WINO_WSCALE;
+    if (!(fabsf(v) <= 60000.f)) { atomicOr(flag, 1); v = 0.f; }
+    const _Float16 hi = (_Float16)v;
+    dst[idx] = part == 0 ? hi : (_Float16)(v - (float)hi);
+}
+
+void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int ctiles, float* dst, int* flag, hipStream_t s) {
+    const int nchunk = cin_pad / 16;
+    const long total = (long)ctiles * 4 * nchunk * 9 * 4 * 64 * 8;
+    hipLaunchKernelGGL(pack_h3w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin, nchunk, total,
+                       (_Float16*)dst, flag);
+}
+
+// 0: launched; 1: this launch has no Winograd form (the caller falls back to conv_h3g_kernel)
+static int launch_h3w(const ConvKArgs& ka, const float* ww, int ctiles, hipStream_t s) {
+    typedef HGGeom<false, true, false> G;
+    constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
+    if (!ww || ka.nskip > 0 || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || !ka.beta) return 1;
+    if (ctiles != (ka.cout_groups + 7) / 8) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    WinoKArgs wa;
+    wa.H = ka.H; wa.W = ka.W; wa.Dv = ka.Dv; wa.Hv = ka.Hv; wa.Wv = ka.Wv; wa.Ho = ka.Ho; wa.Wo = ka.Wo;
+    wa.nchunk = ka.nchunk; wa.cout_groups = ka.cout_groups; wa.flags = ka.flags;
+    wa.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
+    wa.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
+    wa.ntiles = (ka.Dv / 2) * wa.tny * wa.tnx;
+    wa.y = ka.y; wa.dy = ka.dy; wa.out_pstride = ka.out_pstride; wa.out_g0 = ka.out_g0;
+    wa.bias = ka.bias; wa.gout = ka.gout; wa.beta = ka.beta;
+    wa.inv_scale = 1.0f / WINO_WSCALE;
+    // stage order: phase 0 = (xi 1 -> A, xi 2 -> B) per chunk, phase 1 = (xi 0 -> A, xi 3 -> B) per chunk
+    static const int XI[2][2] = {{1, 2}, {0, 3}};
+    static const int PA[4] = {0, 1, 2, 1}, PB[4] = {2, 2, 1, 3};
+    static const float SB[4] = {-1.f, 1.f, -1.f, -1.f};
+    const long plane = (long)ka.H * ka.W * 16;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int chunk = 0; chunk < ka.nchunk; ++chunk)
+            for (int ab = 0; ab < 2; ++ab) {
+                const int xi = XI[ph][ab];
+                const bool second = chunk >= ka.csplit;
+                const long ps = second ? ka.in2_pstride : ka.in_pstride;
+                const char* x = (const char*)(second ? ka.x2 : ka.x);
+                const char* dx = (const char*)(second ? ka.dx2 : ka.dx);
+                const long off = (long)(second ? chunk - ka.csplit : chunk) * 4 * ps * 16;
+                WinoSrc& e = wa.st[(ph * ka.nchunk + chunk) * 2 + ab];
+                e.xa = x + off + PA[xi] * plane; e.xb = x + off + PB[xi] * plane; e.dxd = dx - x;
+                e.w = (const char*)ww + (long)(chunk * 4 + xi) * G::WG * 16; e.psb = ps * 16; e.sb = SB[xi]; e.pad_ = 0;
+            }
+    dim3 grid(wa.ntiles * ctiles, 1, 1), block(512, 1, 1);
+    hipLaunchKernelGGL(conv_h3w_kernel, grid, block, smem, s, wa);
+    return 0;
+}

@@ -179,3 +179,66 @@ def test_dma_addressing_with_bit31_of_the_address_set(engine_factory, prec, monk
     y, dy = L.leaky_relu_vel(y, dy)
     _chk(out["1"][0], y, "conv3 bit31 y", half)
     _chk(out["1"][1], dy, "conv3 bit31 dy", half)
+
+
+GAUGED = [
+    # cin, cout, (D, H, W), act       (Dv = D - 2: even -> the Winograd-z kernel on f16x3, odd -> the direct gauged kernel)
+    (64, 64, (10, 13, 21), True),
+    (64, 64, (6, 10, 40), False),
+    (128, 64, (8, 12, 37), True),        # conv_r00/conv_0: eight chunks, 32 stages
+    (64, 128, (4, 9, 18), True),         # two cout tiles
+    (16, 24, (12, 8, 33), True),         # one chunk, ragged cout
+    (8, 8, (14, 12, 12), False),         # padded chunk of a narrow test model
+    (64, 64, (9, 11, 19), True),         # odd number of output planes: no Winograd form
+    (32, 64, (26, 20, 70), True),        # more plane pairs and patches than one wave of workgroups per XCD
+]
+
+
+@pytest.mark.parametrize("cin,cout,dims,act", GAUGED)
+def test_layer_gauged(eng, cin, cout, dims, act, monkeypatch):
+    """The two-product form of a style-modulated 3x3x3 layer: y = W.x + b, dy = W.dx~ + beta (.) (W.x),
+    through nbe_test_layer_gauged -- conv_h3w_kernel (Winograd F(2,3) along z, one accumulator per output) where it
+    applies, conv_h3g_kernel otherwise and with NBE_WINO=0; the float32 and float16 engines run their own gauged kernels.
+    Weights are unit vectors per output channel, as the modulation leaves them (style_layers_vel.py:84-96)."""
+    from oracle import layers as L
+    rng = np.random.default_rng(4000 + cin * 3 + cout * 5 + dims[0] * 7 + dims[2])
+    x, dx = _rand(rng, cin, *dims), _rand(rng, cin, *dims)
+    w = _rand(rng, cout, cin, 3, 3, 3)
+    w /= np.sqrt((w.astype(np.float64) ** 2).sum(axis=(1, 2, 3, 4), keepdims=True)).astype(np.float32)
+    beta = (0.3 * _rand(rng, cout)).astype(np.float32)
+    b = 0.1 * _rand(rng, cout)
+    half = eng.precision == "f16"
+    w64 = _h(w, half).astype(np.float64)
+    y_o, dy_o = L.conv_layer_vel("conv3", _h(x, half).astype(np.float64), _h(dx, half).astype(np.float64), w64,
+                                 w64 * beta.astype(np.float64)[:, None, None, None, None], b.astype(np.float64))
+    if act:
+        y_o, dy_o = L.leaky_relu_vel(y_o, dy_o)
+    y, dy = eng.test_layer_gauged(x, dx, w, beta, b, act=act)
+    _chk(y, y_o, "gauged primal", half)
+    _chk(dy, dy_o, "gauged tangent", half)
+    if eng.precision == "f16x3":
+        monkeypatch.setenv("NBE_WINO", "0")
+        y0, dy0 = eng.test_layer_gauged(x, dx, w, beta, b, act=act)
+        _chk(y0, y_o, "gauged primal, direct kernel", half)
+        _chk(dy0, dy_o, "gauged tangent, direct kernel", half)
+        print("wino vs direct: y %.2e dy %.2e | vs f64: wino %.2e %.2e direct %.2e %.2e" % (
+            rel_l2(y, y0), rel_l2(dy, dy0), rel_l2(y, y_o), rel_l2(dy, dy_o), rel_l2(y0, y_o), rel_l2(dy0, dy_o)))
+
+
+def test_winograd_pack_refuses_weights_beyond_its_scale(engine_factory):
+    """conv_h3w_kernel scales the weights by 2^14 (unit rows fit with two binades to spare); a weight that would leave
+    the f16 range there clears the context's Winograd flag and the launch runs on the direct kernel: same tolerances."""
+    from oracle import layers as L
+    e = engine_factory(precision="f16x3")
+    rng = np.random.default_rng(5)
+    cin, cout, dims = 32, 64, (6, 9, 20)
+    x, dx = _rand(rng, cin, *dims), _rand(rng, cin, *dims)
+    w = _rand(rng, cout, cin, 3, 3, 3) / np.sqrt(cin * 27.0).astype(np.float32)
+    w[3, 5, 1, 1, 1] = 9.0
+    beta, b = (0.3 * _rand(rng, cout)).astype(np.float32), 0.1 * _rand(rng, cout)
+    w64 = w.astype(np.float64)
+    y_o, dy_o = L.conv_layer_vel("conv3", x.astype(np.float64), dx.astype(np.float64), w64,
+                                 w64 * beta.astype(np.float64)[:, None, None, None, None], b.astype(np.float64))
+    y, dy = e.test_layer_gauged(x, dx, w, beta, b)
+    _chk(y, y_o, "primal")
+    _chk(dy, dy_o, "tangent")
