@@ -66,7 +66,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS, z0 = 2 * zp;
     const int nst = 4 * a.nchunk;
 
-    const unsigned lane16 = (unsigned)lane * 16u;
     const long to = (((long)z0 * a.H + y0) * a.W + x0) * 16;
     const long wcm = (long)ct * nst * WGU * 16;
 
@@ -78,7 +77,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     };
     auto dma_w = [&](int buf, int t) {                           // 36 wave-instructions of weights, 5 slots per wave
         const int n = wave + NW * t;
-        if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, lane16, lds + buf * WGU + n * 64);
+        unsigned l16 = (unsigned)lane;
+        asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(l16));       // recomputed at every use: held in a register it is spilled
+        if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, l16, lds + buf * WGU + n * 64);
     };
     // ---- the transformed patch of the next stage: 24 wave-items (tensor, channel half, 64 units of the 340) of a hi and a
     // lo plane each, three per wave; an item is four 16-byte loads per lane (a hi, a lo, b hi, b lo), 8 channels of
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         const int row = (uu * 241) >> 13, col = uu - row * HP_RS;   // uu / 34 for uu < 384
         return (unsigned)(row * a.W + col) * 16u;
     };
-    half8 sah, sal, sbh, sbl;
-    float ssb = 0.f;
-    auto st_load = [&](int j) {
+    // (the staging registers belong to one stage: declared there, so that nothing is carried across stage boundaries)
+    struct Stg { half8 ah, al, bh, bl; float sb; };
+    auto st_load = [&](int j, Stg& g) {
 #ifdef WX_NOST
         return;
 #endif
@@ -112,24 +113,28 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         auto ld = [&](half8& d, const char* base) {
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(go), "s"(base) : "memory");
         };
-        ld(sah, pa); ld(sal, pa + nx.psb); ld(sbh, pb); ld(sbl, pb + nx.psb);
-        ssb = nx.sb;
+        ld(g.ah, pa); ld(g.al, pa + nx.psb); ld(g.bh, pb); ld(g.bl, pb + nx.psb);
+        g.sb = nx.sb;
     };
-    auto st_store = [&](int j, int buf) {
+    auto st_store = [&](int j, int buf, Stg& g) {
 #ifdef WX_NOST
         return;
 #endif
         half8 hi, lo;
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sah), "+v"(sal), "+v"(sbh), "+v"(sbl));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g.ah), "+v"(g.al), "+v"(g.bh), "+v"(g.bl));
+#ifdef WX_NOXF
+        hi = g.ah + g.bh; lo = g.al + g.bl;
+#else
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float va = (float)sah[e] + (float)sal[e] * H3_INV;
-            const float vb = (float)sbh[e] + (float)sbl[e] * H3_INV;
-            const float v = va + ssb * vb;
+            const float va = (float)g.ah[e] + (float)g.al[e] * H3_INV;
+            const float vb = (float)g.bh[e] + (float)g.bl[e] * H3_INV;
+            const float v = va + g.sb * vb;
             hi[e] = (_Float16)v;
             lo[e] = (_Float16)((v - (float)hi[e]) * H3_SCALE);
             if (e == 3) __builtin_amdgcn_sched_barrier(0);       // four channels at a time: half the temporaries
         }
+#endif
         bool valid;
         const int n = wave + NW * j;
         const int lo_ = XBASE + buf * HQ_XB + (n / 12) * HQ_XT + (((n % 12) / 6) * 2) * HQ_PP + item_unit(j, valid);
@@ -196,9 +201,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         LA(wl, wa + CT + aP);
         NBE_SB; MM8(DY, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px); NBE_SB;
         mid();
-        preXl();
         NBE_SB; MM8(DY, wh, dxl, -1, nb, px, false, true); NBE_SB;
-        preW();
+        preXl(); preW();                                                                  // (not earlier: registers)
         NBE_SB; MM8(Y, wl, xh, -1, nb, px); NBE_SB;                                       // lo(w) . hi(x)
         preXh();
         NBE_SB; MM8(DY, wl, dxh, -1, nb, px); NBE_SB;
@@ -207,47 +211,55 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
     auto stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s) {
         const bool px = s + 1 < nst;
+        // the first operands of stage s+1 are requested under the last products of stage s -- except across the phase
+        // boundary, where they would only be carried through the butterfly (registers): it requests them itself
+        const bool pre = px && s + 1 != 2 * a.nchunk;
         if (px) set_next(s + 1);
         // (the buffer parity is a compile-time constant of each instantiation: hidden from the compiler, which would
         // otherwise precompute one address register per LDS read of the stage -- dozens, spilled)
         int par = s & 1;
         asm volatile("" : "+s"(par));
-        const int nb = 1 - par;
+        int nb = 1 - par;
+        asm volatile("" : "+s"(nb));
         const int wb = par * WGU, xb = XBASE + par * HQ_XB;
-        const int wbn = WGU - wb, xbn = XBASE + nb * HQ_XB;
-        if (px) st_load(0);
+        const int wbn = nb * WGU, xbn = XBASE + nb * HQ_XB;
+        Stg g;
+        if (px) st_load(0, g);
         pair(Y, DY, 0, nb, px, wb, xb + bP1,                                              // taps (0,1) + the weight DMA of stage s+1
              [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
              [&] {});
-        if (px) { st_store(0, nb); st_load(1); }
+        if (px) { st_store(0, nb, g); st_load(1, g); }
         half8 a1[MT], a2[MT], b1x[NT], b1d[NT];
         // single tap 4 = (dy 1, dx 1): the K halves select the PART: [wh | wh 2^-11] . [xh | xl] and [wl | 0] . [xh | xl]
         const int aS = wb + 4 * TAPU + (2 * kh) * CT + c;
         const int bS = xb + (2 * kh + ks) * HQ_PP + rowp * HP_RS + c + SH4;
         pair(Y, DY, -1, nb, px, wb + 2 * TAPU, xb + 2 + bP32,                             // taps (2,3)
-             [&] { LB(b1x, bS); }, [&] { LA(a1, aS); LA(a2, aS + CT); }, [&] { LB(b1d, bS + HQ_XT); }, [&] {});
+             [&] { LB(b1x, bS); }, [&] { LA(a1, aS); }, [&] { LB(b1d, bS + HQ_XT); }, [&] {});
+        const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         {
-            const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
             const _Float16 m1 = ks ? kInv : (_Float16)1.0f;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { a1[mt] = a1[mt] * m1; a2[mt] = ks ? zero : a2[mt]; }
+            for (int mt = 0; mt < MT; ++mt) a1[mt] = a1[mt] * m1;
         }
         NBE_SB; MM8(Y, a1, b1x, -1, 0, false, true); NBE_SB;
+        LA(a2, aS + CT);                                                                  // (only now: four A operand sets at once do not fit)
         LB(xl, xb + SH5 + bP32 + HQ_PP);
         NBE_SB; MM8(DY, a1, b1d, -1, 0, false); NBE_SB;
         LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a2[mt] = ks ? zero : a2[mt];
         NBE_SB; MM8(Y, a2, b1x, -1, 0, false, true); NBE_SB;
         MM8(DY, a2, b1d, -1, 0, false); NBE_SB;
-        if (px) { st_store(1, nb); st_load(2); }
+        if (px) { st_store(1, nb, g); st_load(2, g); }
         pair(Y, DY, -1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                           // taps (5,6)
              [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
              [&] {});
-        if (px) st_store(2, nb);
+        if (px) st_store(2, nb, g);
         // taps (7,8); the stage's one barrier sits after the third product: by then this wave has read everything it
         // needs from the buffers of stage s, and the patch and weights of stage s+1 are complete once every wave has
         // waited for its own stores and DMA
         pair(Y, DY, -1, nb, px, wb + 7 * TAPU, xb + SH7 + bP1,
-             [&] { if (px) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (px) LA(wh, wbn + aP); }, [&] { if (px) LB(xh, xbn + bP1); },
+             [&] { if (pre) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (pre) LA(wh, wbn + aP); }, [&] { if (pre) LB(xh, xbn + bP1); },
              [&] { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); });
     };
 
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
         for (int k = 0; k < G::NWS; ++k) dma_w(0, k);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { st_load(j); st_store(j, 0); }
+        for (int j = 0; j < 3; ++j) { Stg g; st_load(j, g); st_store(j, 0, g); }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         LA(wh, aP); LB(xl, XBASE + bP1 + HQ_PP); LB(xh, XBASE + bP1);
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_nop 7" ::: "memory");                 // accumulator writes -> the next MFMAs' C operands
+            LA(wh, aP); LB(xl, XBASE + bP1 + HQ_PP); LB(xh, XBASE + bP1);   // stage 2 * nchunk reads buffers 0
         }
 #endif
         stage(YA, DA, 2 * s2);
