@@ -106,14 +106,31 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         const long po = ((n / 12) ? nx.dxd : 0) + (long)(((n % 12) / 6) * 2) * nx.psb;
         const char* pa = nx.xa + po;
         const char* pb = nx.xb + po;
-        // wave-uniform base in SGPRs + 32-bit lane offset (the compiler's own form keeps a 64-bit address per lane and load);
-        // asm loads are invisible to the compiler's vmcnt bookkeeping: st_store waits for them itself
         bool valid;
         const unsigned go = item_goff(item_unit(j, valid));
-        auto ld = [&](half8& d, const char* base) {
+        // buffer loads: wave-uniform base in a resource descriptor (SGPRs) + 32-bit lane offset (+ the lo plane's distance as
+        // the scalar offset) -- the compiler's own global loads keep a 64-bit address per lane and load.  Unlike loads
+        // issued from asm statements these are visible to the compiler's vmcnt bookkeeping (spill-safe, counted waits).
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, 0x7fffffff, 0x00027000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7fffffff, 0x00027000);
+        const unsigned pso = (unsigned)nx.psb;                   // < 2^31 - patch extent: checked by the launcher
+        auto ld = [&](half8& d, __amdgpu_buffer_rsrc_t r, unsigned so) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, go, so, 0);
+            d = __builtin_bit_cast(half8, v);
+        };
+#ifdef WX_NOLD
+        asm volatile("" : "=v"(g.ah), "=v"(g.al), "=v"(g.bh), "=v"(g.bl) : "v"(go), "s"(pa), "s"(pb));
+#else
+#ifdef WX_ASMLD
+        auto lda = [&](half8& d, const char* base) {
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(go), "s"(base) : "memory");
         };
-        ld(g.ah, pa); ld(g.al, pa + nx.psb); ld(g.bh, pb); ld(g.bl, pb + nx.psb);
+        lda(g.ah, pa); lda(g.al, pa + nx.psb); lda(g.bh, pb); lda(g.bl, pb + nx.psb);
+#else
+        ld(g.ah, ra, 0); ld(g.al, ra, pso); ld(g.bh, rb, 0); ld(g.bl, rb, pso);
+#endif
+#endif
         g.sb = nx.sb;
     };
     auto st_store = [&](int j, int buf, Stg& g) {
@@ -121,18 +138,39 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         return;
 #endif
         half8 hi, lo;
+#ifdef WX_ASMLD
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(g.ah), "+v"(g.al), "+v"(g.bh), "+v"(g.bl));
+#endif
 #ifdef WX_NOXF
         hi = g.ah + g.bh; lo = g.al + g.bl;
 #else
+        {
+            // V = (a hi + 2^-11 a lo) + sb (b hi + 2^-11 b lo) on two channels per register with the mixed-precision FMA
+            // (f16 sources widened in the instruction: no conversions), then hi = f16(V), lo = f16((V - hi) 2^11):
+            // 11 VALU operations per channel pair (the compiler's own form of the same arithmetic: 17)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 AH = __builtin_bit_cast(u32x4, g.ah), AL = __builtin_bit_cast(u32x4, g.al);
+            const u32x4 BH = __builtin_bit_cast(u32x4, g.bh), BL = __builtin_bit_cast(u32x4, g.bl);
+            u32x4 HI, LO;
+            const float inv = H3_INV, sinv = g.sb * H3_INV, sb = g.sb, k2048 = H3_SCALE;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float va = (float)g.ah[e] + (float)g.al[e] * H3_INV;
-            const float vb = (float)g.bh[e] + (float)g.bl[e] * H3_INV;
-            const float v = va + g.sb * vb;
-            hi[e] = (_Float16)v;
-            lo[e] = (_Float16)((v - (float)hi[e]) * H3_SCALE);
-            if (e == 3) __builtin_amdgcn_sched_barrier(0);       // four channels at a time: half the temporaries
+            for (int r = 0; r < 4; ++r) {
+                float t0, t1;
+                unsigned h, l;
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t0) : "v"(AL[r]), "s"(inv), "v"(AH[r]));
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(t1) : "v"(AL[r]), "s"(inv), "v"(AH[r]));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(t0) : "v"(BL[r]), "s"(sinv));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t1) : "v"(BL[r]), "s"(sinv));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(t0) : "v"(BH[r]), "s"(sb));
+                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t1) : "v"(BH[r]), "s"(sb));
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(t0), "v"(t1));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(t0) : "v"(h));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t1) : "v"(h));
+                asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l) : "v"(t0), "s"(k2048));
+                asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l) : "v"(t1), "s"(k2048));
+                HI[r] = h; LO[r] = l;
+            }
+            hi = __builtin_bit_cast(half8, HI); lo = __builtin_bit_cast(half8, LO);
         }
 #endif
         bool valid;
@@ -188,20 +226,30 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         }
     };
 #define NBE_SB __builtin_amdgcn_sched_barrier(0)
-    half8 wh[MT], wl[MT], xh[NT], xl[NT], dxh[NT], dxl[NT];
+    half8 wh[MT], wl[MT], wp[MT], xh[NT], xl[NT], dxh[NT], dxl[NT];
     // A tap pair: six products into (Y, DY).  On entry wh, xl and xh of the pair are loaded (or in flight); preXl / preW /
     // preXh request those of whatever follows as soon as the registers are free.  Dependent MFMAs are >= 8 MFMAs apart.
     // (mid: after the third product every LDS read of the pair has been issued -- the stage's barrier goes there)
     auto pair = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int slot0, int nb, bool px, int wa, int xp,
                     auto&& preXl, auto&& preW, auto&& preXh, auto&& mid) {
         LB(dxh, xp + HQ_XT);
+#ifndef WX_SCALE2
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wp[mt] = wh[mt] * kInv;                           // once per pair (two products use it)
+        NBE_SB; MM8(Y, wp, xl, slot0, nb, px, true); NBE_SB;                              // hi(w) 2^-11 . lo(x)
+#else
         NBE_SB; MM8(Y, wh, xl, slot0, nb, px, false, true); NBE_SB;                       // hi(w) 2^-11 . lo(x)
+#endif
         LB(dxl, xp + HQ_XT + HQ_PP);
         NBE_SB; MM8(Y, wh, xh, slot0 < 0 ? -1 : slot0 + 2, nb, px); NBE_SB;               // hi . hi
         LA(wl, wa + CT + aP);
         NBE_SB; MM8(DY, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px); NBE_SB;
         mid();
+#ifndef WX_SCALE2
+        NBE_SB; MM8(DY, wp, dxl, -1, nb, px); NBE_SB;
+#else
         NBE_SB; MM8(DY, wh, dxl, -1, nb, px, false, true); NBE_SB;
+#endif
         preXl(); preW();                                                                  // (not earlier: registers)
         NBE_SB; MM8(Y, wl, xh, -1, nb, px); NBE_SB;                                       // lo(w) . hi(x)
         preXh();
@@ -210,11 +258,15 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
     auto stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s) {
+#ifdef WX_NOBR
+        const bool px = true;
+#else
         const bool px = s + 1 < nst;
+#endif
         // the first operands of stage s+1 are requested under the last products of stage s -- except across the phase
         // boundary, where they would only be carried through the butterfly (registers): it requests them itself
         const bool pre = px && s + 1 != 2 * a.nchunk;
-        if (px) set_next(s + 1);
+        if (px) set_next(s + 1 < nst ? s + 1 : 0);
         // (the buffer parity is a compile-time constant of each instantiation: hidden from the compiler, which would
         // otherwise precompute one address register per LDS read of the stage -- dozens, spilled)
         int par = s & 1;
@@ -265,6 +317,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 
     // ---- prologue: stage 0
     {
+#ifdef WX_NOST
+        for (int i = tid; i < 2 * HQ_XB; i += 512) lds[XBASE + i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         set_next(0);
 #pragma unroll
         for (int k = 0; k < G::NWS; ++k) dma_w(0, k);
@@ -408,6 +463,8 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, int ctiles, hipStrea
     constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
     if (!ww || ka.nskip > 0 || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || !ka.beta) return 1;
     if (ctiles != (ka.cout_groups + 7) / 8) return 1;
+    // the raw planes are fetched with buffer loads: lane offset + hi -> lo plane distance must stay below 2^31
+    if (std::max(ka.in_pstride, ka.csplit < ka.nchunk ? ka.in2_pstride : 0L) * 16 + 16L * (HP_ROWS + 2) * ka.W >= (1L << 31)) return 1;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
