@@ -87,7 +87,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // (per-lane offsets are recomputed at every use -- a dozen VALU operations per item -- instead of held in registers)
     auto item_unit = [&](int j, bool& valid) {                   // unit 0..339 of the 10 x 34 patch plane this lane handles in item j
         int l = lane;
+#ifndef WX_HOIST
         asm volatile("" : "+v"(l));                              // (or the compiler hoists the offsets out of the loop and spills them)
+#endif
         const int u = ((wave + NW * j) % 6) * 64 + l;
         valid = u < HP_PL;
         return valid ? u : HP_PL - 1;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         const int row = (uu * 241) >> 13, col = uu - row * HP_RS;   // uu / 34 for uu < 384
         return (unsigned)(row * a.W + col) * 16u;
     };
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     // (the staging registers belong to one stage: declared there, so that nothing is carried across stage boundaries)
     struct Stg { half8 ah, al, bh, bl; float sb; };
     auto st_load = [&](int j, Stg& g) {
@@ -111,7 +114,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         // buffer loads: wave-uniform base in a resource descriptor (SGPRs) + 32-bit lane offset (+ the lo plane's distance as
         // the scalar offset) -- the compiler's own global loads keep a 64-bit address per lane and load.  Unlike loads
         // issued from asm statements these are visible to the compiler's vmcnt bookkeeping (spill-safe, counted waits).
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, 0x7fffffff, 0x00027000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7fffffff, 0x00027000);
         const unsigned pso = (unsigned)nx.psb;                   // < 2^31 - patch extent: checked by the launcher
@@ -133,53 +135,57 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #endif
         g.sb = nx.sb;
     };
-    auto st_store = [&](int j, int buf, Stg& g) {
+    // V = (a hi + 2^-11 a lo) + sb (b hi + 2^-11 b lo) on two channels per register with the mixed-precision FMA (f16
+    // sources widened in the instruction: no conversions), then hi = f16(V), lo = f16((V - hi) 2^11): 11 VALU operations
+    // per channel pair (the compiler's own form of the same arithmetic: 17).  Sixteen micro-steps of two or three
+    // operations each: in the loop one follows every MFMA of two products, where it issues in the MFMA's shadow -- all
+    // waves of a workgroup reach the same point of a stage together, so a block of VALU work stalls the matrix pipe of
+    // its SIMD for its whole length (measured: 3.2 VALU per MFMA and 56 % matrix-busy with the transform in blocks).
+    struct Xf { u32x4 HI, LO; float t0, t1; unsigned h; };
+    auto xf_step = [&](const Stg& g, Xf& x, int k) {
 #ifdef WX_NOST
         return;
 #endif
-        half8 hi, lo;
-#ifdef WX_ASMLD
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g.ah), "+v"(g.al), "+v"(g.bh), "+v"(g.bl));
-#endif
-#ifdef WX_NOXF
-        hi = g.ah + g.bh; lo = g.al + g.bl;
-#else
-        {
-            // V = (a hi + 2^-11 a lo) + sb (b hi + 2^-11 b lo) on two channels per register with the mixed-precision FMA
-            // (f16 sources widened in the instruction: no conversions), then hi = f16(V), lo = f16((V - hi) 2^11):
-            // 11 VALU operations per channel pair (the compiler's own form of the same arithmetic: 17)
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 AH = __builtin_bit_cast(u32x4, g.ah), AL = __builtin_bit_cast(u32x4, g.al);
-            const u32x4 BH = __builtin_bit_cast(u32x4, g.bh), BL = __builtin_bit_cast(u32x4, g.bl);
-            u32x4 HI, LO;
-            const float inv = H3_INV, sinv = g.sb * H3_INV, sb = g.sb, k2048 = H3_SCALE;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t0, t1;
-                unsigned h, l;
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t0) : "v"(AL[r]), "s"(inv), "v"(AH[r]));
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(t1) : "v"(AL[r]), "s"(inv), "v"(AH[r]));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(t0) : "v"(BL[r]), "s"(sinv));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t1) : "v"(BL[r]), "s"(sinv));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(t0) : "v"(BH[r]), "s"(sb));
-                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t1) : "v"(BH[r]), "s"(sb));
-                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(t0), "v"(t1));
-                asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(t0) : "v"(h));
-                asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t1) : "v"(h));
-                asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l) : "v"(t0), "s"(k2048));
-                asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l) : "v"(t1), "s"(k2048));
-                HI[r] = h; LO[r] = l;
-            }
-            hi = __builtin_bit_cast(half8, HI); lo = __builtin_bit_cast(half8, LO);
+        const int r = k >> 2, m = k & 3;
+        const unsigned AH = __builtin_bit_cast(u32x4, g.ah)[r], AL = __builtin_bit_cast(u32x4, g.al)[r];
+        const unsigned BH = __builtin_bit_cast(u32x4, g.bh)[r], BL = __builtin_bit_cast(u32x4, g.bl)[r];
+        const float inv = H3_INV, sinv = g.sb * H3_INV, sb = g.sb, k2048 = H3_SCALE;
+        if (m == 0) {
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x.t0) : "v"(AL), "s"(inv), "v"(AH));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(BL), "s"(sinv));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(BH), "s"(sb));
+        } else if (m == 1) {
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x.t1) : "v"(AL), "s"(inv), "v"(AH));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(BL), "s"(sinv));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(BH), "s"(sb));
+        } else if (m == 2) {
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x.h) : "v"(x.t0), "v"(x.t1));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(x.h));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(x.h));
+        } else {
+            unsigned l;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l) : "v"(x.t0), "s"(k2048));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l) : "v"(x.t1), "s"(k2048));
+            x.HI[r] = x.h; x.LO[r] = l;
         }
+    };
+    auto st_write = [&](int j, int buf, const Xf& x) {
+#ifdef WX_NOST
+        return;
 #endif
         bool valid;
         const int n = wave + NW * j;
         const int lo_ = XBASE + buf * HQ_XB + (n / 12) * HQ_XT + (((n % 12) / 6) * 2) * HQ_PP + item_unit(j, valid);
         if (valid) {
-            L8w[lo_] = hi;
-            L8w[lo_ + HQ_PP] = lo;
+            L8w[lo_] = __builtin_bit_cast(half8, x.HI);
+            L8w[lo_ + HQ_PP] = __builtin_bit_cast(half8, x.LO);
         }
+    };
+    auto st_store = [&](int j, int buf, Stg& g) {                // the same in one block (prologue)
+        Xf x;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xf_step(g, x, k);
+        st_write(j, buf, x);
     };
 
     f32x4 YA[NTILE], DA[NTILE], YB[NTILE], DB[NTILE];            // AGPRs, updated in place (see conv_h3q_kernel)
@@ -209,16 +215,32 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     };
     const _Float16 kInv = (_Float16)H3_INV;
     // one product on the wave tile; slot >= 0: weight-DMA slots `slot`, `slot + 1` after the two halves of the product
-    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px, bool zsel = false,
-                   bool sc = false /* A times 2^-11, one row of tiles at a time */) {
-        half8 as;
+    auto nohook = [](int) {};
+    // (hook(t) runs after MFMA t: a micro-step of VALU work that issues while the matrix pipe is busy with that MFMA)
+    auto MM8h = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px, bool zsel,
+                    bool hooked, auto&& hook) {
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
-            if (sc) {
-                if ((t % NT) == 0) { as = A[t / NT] * kInv; mmz(acc[t], as, B[t % NT]); } else mm(acc[t], as, B[t % NT]);
-            } else
             if (zsel && (t % NT) == 0) mmz(acc[t], A[t / NT], B[t % NT]); else
             mm(acc[t], A[t / NT], B[t % NT]);
+            if (hooked) { hook(t); __builtin_amdgcn_sched_barrier(0); }
+            if (slot >= 0 && (t % 4) == 3) {
+                if (px) dma_w(nb, slot + t / 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto MM8 = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px, bool zsel = false) {
+        MM8h(acc, A, B, slot, nb, px, zsel, false, nohook);
+    };
+    // the first product of a pair, hi(w) 2^-11 . lo(x): the scaled operands are made on the way (one row of tiles ahead of
+    // its MFMAs) and kept in wp for the pair's fourth product
+    auto MM8s = [&](f32x4 (&acc)[NTILE], half8 (&P)[MT], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px) {
+        P[0] = A[0] * kInv;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            if ((t % NT) == 0) { if (t / NT + 1 < MT) P[t / NT + 1] = A[t / NT + 1] * kInv; mmz(acc[t], P[t / NT], B[t % NT]); }
+            else mm(acc[t], P[t / NT], B[t % NT]);
             if (slot >= 0 && (t % 4) == 3) {
                 if (px) dma_w(nb, slot + t / 4);
                 __builtin_amdgcn_sched_barrier(0);
@@ -231,25 +253,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // preXh request those of whatever follows as soon as the registers are free.  Dependent MFMAs are >= 8 MFMAs apart.
     // (mid: after the third product every LDS read of the pair has been issued -- the stage's barrier goes there)
     auto pair = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int slot0, int nb, bool px, int wa, int xp,
-                    auto&& preXl, auto&& preW, auto&& preXh, auto&& mid) {
+                    auto&& preXl, auto&& preW, auto&& preXh, auto&& mid, bool hooked, auto&& hook, auto&& after3) {
         LB(dxh, xp + HQ_XT);
-#ifndef WX_SCALE2
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) wp[mt] = wh[mt] * kInv;                           // once per pair (two products use it)
-        NBE_SB; MM8(Y, wp, xl, slot0, nb, px, true); NBE_SB;                              // hi(w) 2^-11 . lo(x)
-#else
-        NBE_SB; MM8(Y, wh, xl, slot0, nb, px, false, true); NBE_SB;                       // hi(w) 2^-11 . lo(x)
-#endif
+        NBE_SB; MM8s(Y, wp, wh, xl, slot0, nb, px); NBE_SB;                               // hi(w) 2^-11 . lo(x)
         LB(dxl, xp + HQ_XT + HQ_PP);
-        NBE_SB; MM8(Y, wh, xh, slot0 < 0 ? -1 : slot0 + 2, nb, px); NBE_SB;               // hi . hi
+        NBE_SB; MM8h(Y, wh, xh, slot0 < 0 ? -1 : slot0 + 2, nb, px, false, hooked, [&](int t) { hook(t); }); NBE_SB;       // hi . hi
         LA(wl, wa + CT + aP);
-        NBE_SB; MM8(DY, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px); NBE_SB;
+        NBE_SB; MM8h(DY, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px, false, hooked, [&](int t) { hook(8 + t); }); NBE_SB;
+        after3();
         mid();
-#ifndef WX_SCALE2
         NBE_SB; MM8(DY, wp, dxl, -1, nb, px); NBE_SB;
-#else
-        NBE_SB; MM8(DY, wh, dxl, -1, nb, px, false, true); NBE_SB;
-#endif
         preXl(); preW();                                                                  // (not earlier: registers)
         NBE_SB; MM8(Y, wl, xh, -1, nb, px); NBE_SB;                                       // lo(w) . hi(x)
         preXh();
@@ -257,16 +270,14 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     };
 
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
-    auto stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s) {
-#ifdef WX_NOBR
-        const bool px = true;
-#else
-        const bool px = s + 1 < nst;
-#endif
+    // (pxc: a stage follows -- a compile-time constant, so that the fetch of the next stage costs no branches; only the
+    // last stage of a workgroup runs the other instantiation)
+    auto stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s, auto pxc) {
+        constexpr bool px = decltype(pxc)::value;
         // the first operands of stage s+1 are requested under the last products of stage s -- except across the phase
         // boundary, where they would only be carried through the butterfly (registers): it requests them itself
         const bool pre = px && s + 1 != 2 * a.nchunk;
-        if (px) set_next(s + 1 < nst ? s + 1 : 0);
+        if (px) set_next(s + 1);
         // (the buffer parity is a compile-time constant of each instantiation: hidden from the compiler, which would
         // otherwise precompute one address register per LDS read of the stage -- dozens, spilled)
         int par = s & 1;
@@ -275,18 +286,23 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         asm volatile("" : "+s"(nb));
         const int wb = par * WGU, xb = XBASE + par * HQ_XB;
         const int wbn = nb * WGU, xbn = XBASE + nb * HQ_XB;
+        // the transformed patch of stage s+1: item j is loaded, transformed under the second and third product of a later
+        // pair (one micro-step per MFMA) and written after that pair's third product; the next item's loads follow at once
         Stg g;
+        Xf xf;
+        auto hk = [&](int k) { xf_step(g, xf, k); };
+        auto none = [] {};
         if (px) st_load(0, g);
         pair(Y, DY, 0, nb, px, wb, xb + bP1,                                              // taps (0,1) + the weight DMA of stage s+1
              [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
-             [&] {});
-        if (px) { st_store(0, nb, g); st_load(1, g); }
+             none, false, nohook, none);
         half8 a1[MT], a2[MT], b1x[NT], b1d[NT];
         // single tap 4 = (dy 1, dx 1): the K halves select the PART: [wh | wh 2^-11] . [xh | xl] and [wl | 0] . [xh | xl]
         const int aS = wb + 4 * TAPU + (2 * kh) * CT + c;
         const int bS = xb + (2 * kh + ks) * HQ_PP + rowp * HP_RS + c + SH4;
         pair(Y, DY, -1, nb, px, wb + 2 * TAPU, xb + 2 + bP32,                             // taps (2,3)
-             [&] { LB(b1x, bS); }, [&] { LA(a1, aS); }, [&] { LB(b1d, bS + HQ_XT); }, [&] {});
+             [&] { LB(b1x, bS); }, [&] { LA(a1, aS); }, [&] { LB(b1d, bS + HQ_XT); }, none,
+             px, hk, [&] { if (px) { st_write(0, nb, xf); st_load(1, g); } });
         const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
         {
             const _Float16 m1 = ks ? kInv : (_Float16)1.0f;
@@ -302,17 +318,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         for (int mt = 0; mt < MT; ++mt) a2[mt] = ks ? zero : a2[mt];
         NBE_SB; MM8(Y, a2, b1x, -1, 0, false, true); NBE_SB;
         MM8(DY, a2, b1d, -1, 0, false); NBE_SB;
-        if (px) { st_store(1, nb, g); st_load(2, g); }
         pair(Y, DY, -1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                           // taps (5,6)
              [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
-             [&] {});
-        if (px) st_store(2, nb, g);
+             none, px, hk, [&] { if (px) { st_write(1, nb, xf); st_load(2, g); } });
         // taps (7,8); the stage's one barrier sits after the third product: by then this wave has read everything it
         // needs from the buffers of stage s, and the patch and weights of stage s+1 are complete once every wave has
         // waited for its own stores and DMA
         pair(Y, DY, -1, nb, px, wb + 7 * TAPU, xb + SH7 + bP1,
              [&] { if (pre) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (pre) LA(wh, wbn + aP); }, [&] { if (pre) LB(xh, xbn + bP1); },
-             [&] { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); });
+             [&] { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); },
+             px, hk, [&] { if (px) st_write(2, nb, xf); });
     };
 
     // ---- prologue: stage 0
@@ -330,9 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         LA(wh, aP); LB(xl, XBASE + bP1 + HQ_PP); LB(xh, XBASE + bP1);
     }
 
-    for (int s2 = 0; s2 < 2 * a.nchunk; ++s2) {
-#ifndef WX_NOBF
-        if (s2 == a.nchunk) {
+    auto butterfly = [&] {
             // end of phase 1: A = M1, B = M2  ->  A = M1 + M2, B = M1 - M2
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA results -> accumulator reads
 #pragma unroll
@@ -352,11 +365,22 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             }
             asm volatile("s_nop 7" ::: "memory");                 // accumulator writes -> the next MFMAs' C operands
             LA(wh, aP); LB(xl, XBASE + bP1 + HQ_PP); LB(xh, XBASE + bP1);   // stage 2 * nchunk reads buffers 0
-        }
+    };
+    // the last pair of stages runs outside the loop: its second stage fetches nothing (the other instantiation), and a
+    // branch between the two instantiations inside the loop would merge two versions of every accumulator
+    const int npairs = 2 * a.nchunk;
+    for (int s2 = 0; s2 + 1 < npairs; ++s2) {
+#ifndef WX_NOBF
+        if (s2 == a.nchunk) butterfly();
 #endif
-        stage(YA, DA, 2 * s2);
-        stage(YB, DB, 2 * s2 + 1);
+        stage(YA, DA, 2 * s2, std::true_type());
+        stage(YB, DB, 2 * s2 + 1, std::true_type());
     }
+#ifndef WX_NOBF
+    if (npairs - 1 == a.nchunk) butterfly();
+#endif
+    stage(YA, DA, 2 * npairs - 2, std::true_type());
+    stage(YB, DB, 2 * npairs - 1, std::false_type());
 #undef NBE_SB
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
 
