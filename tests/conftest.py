@@ -48,6 +48,16 @@ def _release_cached_engines():
         pass
 
 
+@pytest.fixture
+def direct_kernels(monkeypatch):
+    """Tests that compare two SCHEDULES of the same box bit for bit (tile merging, roll equivariance) run on the direct gauged
+    kernel: conv_h3w_kernel (Winograd F(2,3) along z, the default for the blocks' conv_0 layers) pairs planes from the first
+    plane of a launch and applies to an even number of planes only, so a voxel's rounding depends on where a tile or slab
+    starts.  The schedules themselves do not depend on the kernel; tests/test_gpu_api.py::
+    test_winograd_schedules_agree_to_rounding holds the default against them at float32 tolerances."""
+    monkeypatch.setenv("NBE_WINO", "0")
+
+
 def rel_l2(a, b):
     import numpy as np
     a = np.asarray(a, dtype=np.float64)

@@ -190,6 +190,7 @@ def test_resident_tensors_and_region_path():
     assert torch.equal(dis, d2) and torch.equal(vel, v2)
 
 
+@pytest.mark.usefixtures("direct_kernels")
 def test_internal_tile_merging_is_exact():
     """nbe_plan_tiles: merging sub-boxes into larger internal tiles (crop % 8 == 0) must not change the
     result beyond rounding, and must be refused when crop % 8 != 0."""
@@ -217,6 +218,47 @@ def test_internal_tile_merging_is_exact():
         eng.set_max_tile(512)
     _close(d1, d0, 1e-6, 1e-5, "merged tiles disp")
     _close(v1, v0, 1e-6, 1e-5, "merged tiles vel")
+
+
+def test_winograd_schedules_agree_to_rounding(monkeypatch):
+    """The default runs the blocks' conv_0 layers on conv_h3w_kernel (Winograd F(2,3) along z), whose rounding depends on
+    how a launch pairs its planes -- hence on the schedule.  Against the direct-kernel field (NBE_WINO=0, what the
+    schedule-equivalence tests compare bit for bit) the default must agree to float32 rounding, on the merged tile and on
+    the caller's grid: displacement everywhere; velocity in the median and in relative L2 over the voxels that no LeakyReLU
+    kink separates (tests/test_gpu_range.py::_kink_robust_vel has the reasoning; a kink flips where a pre-activation is zero
+    to within rounding and moves that voxel's tangent by up to a factor 100)."""
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
+    p = _synthetic(13, 8)
+    eng = get_engine(m, 0)
+    eng.ensure_params(p, False)
+    size, ndiv = (32, 16, 16), (4, 2, 2)
+    box = np.random.default_rng(2).standard_normal((3,) + size).astype(np.float32)
+    proc = J.SubboxProcessor(m, p, J.SubboxConfig(size=size, ndiv=ndiv))
+    out = {}
+    try:
+        for wino in ("0", "1"):
+            monkeypatch.setenv("NBE_WINO", wino)
+            for mt in (0, 512):
+                eng.set_max_tile(mt)
+                eng.profile_reset(); eng.profile_enable(True)
+                out[wino, mt] = proc.process_box(box, Z, OM, show_progress=False)
+                eng.profile_enable(False)
+                names = [k["kernel"] for k in eng.profile_read()]
+                assert any(n.startswith("conv_h3w") for n in names) == (wino == "1"), (wino, names)
+    finally:
+        eng.set_max_tile(512)
+    d_ref, v_ref = out["0", 512]
+    assert np.array_equal(out["0", 0][0], d_ref) and np.array_equal(out["0", 0][1], v_ref)      # direct kernel: schedules agree bit for bit
+    rms_v = np.sqrt(np.mean(v_ref.astype(np.float64) ** 2))
+    for mt in (0, 512):
+        d, v = out["1", mt]
+        _close(d, d_ref, 3e-6, 3e-5, "winograd disp (max_tile %d)" % mt)
+        e = np.abs(v.astype(np.float64) - v_ref) / rms_v
+        inl = e <= 1e-3
+        stats = (float(np.median(e)), float(np.sqrt(np.sum(((v - v_ref) ** 2)[inl])) / np.linalg.norm(v_ref)), float((~inl).mean()))
+        print("winograd vs direct, max_tile %d: vel median %.2e inlier rel_l2 %.2e outliers %.4f" % ((mt,) + stats))
+        assert stats[0] <= 5e-6 and stats[1] <= 1e-4 and stats[2] <= 0.05, stats
 
 
 def test_z_slab_schedule_is_identical():
@@ -395,6 +437,7 @@ def test_graph_replay_is_identical(prec, monkeypatch):
     eng.set_max_tile(512)
 
 
+@pytest.mark.usefixtures("direct_kernels")
 def test_config3_at_full_size_merged_tiles_vs_callers_grid():
     """BASELINE config 3: 512^3 box, ndiv=(4,4,4), compute_vel=True, production width, resident tensors.
     Size-independent property: the engine's default execution (merged tiles: four of 352 x 352 x 608 input when

@@ -116,11 +116,12 @@ def test_gauged_tangent_paths(engine_factory, small, monkeypatch, prec):
     _check(dt, vt, dt_o[0], vt_o[0], "tiny style factor")
 
 
-@pytest.mark.parametrize("switch", ["NBE_H3G_TALL", "NBE_STEM", "NBE_UP8", "NBE_NARROW", "NBE_H3G_BIG"])
+@pytest.mark.parametrize("switch", ["NBE_H3G_TALL", "NBE_STEM", "NBE_UP8", "NBE_NARROW", "NBE_H3G_BIG", "NBE_WINO"])
 def test_kernel_ab_switches_keep_parity(engine_factory, small, monkeypatch, switch):
     """Every A/B switch of the f16x3 velocity path selects kernels that stay held to the oracle: the 2 x 4 wave tile of
     conv_h3g_kernel (its zero-select once sat next to an asm MFMA, tests/test_mfma_hazards.py), the general first-layer kernel,
-    eight up-sampling launches, the wide tile for the head, and the rejected 4 x 4 one-wave-per-SIMD tile."""
+    eight up-sampling launches, the wide tile for the head, the rejected 4 x 4 one-wave-per-SIMD tile, and the direct gauged
+    kernel in place of the Winograd-z one (conv_h3w_kernel)."""
     p, x, d_o, v_o = small
     monkeypatch.setenv(switch, "1" if switch == "NBE_H3G_BIG" else "0")       # (the 4 x 4 tile is off by default)
     e = engine_factory(mid_chan=8, compute_vel=True, precision="f16x3")
@@ -135,6 +136,8 @@ def test_kernel_ab_switches_keep_parity(engine_factory, small, monkeypatch, swit
         assert not any(n.startswith("stem_h3") for n in names)
     if switch == "NBE_UP8":
         assert not any(n.startswith("up_h3") for n in names)
+    if switch == "NBE_WINO":
+        assert not any(n.startswith("conv_h3w") for n in names)
     monkeypatch.delenv(switch)
     e = engine_factory(mid_chan=8, compute_vel=True, precision="f16x3")     # (the head's tile is wired when the weights load)
     e.load_params(p, premodulated=False)
@@ -145,6 +148,7 @@ def test_kernel_ab_switches_keep_parity(engine_factory, small, monkeypatch, swit
     names = [k["kernel"] for k in e.profile_read()]
     _check(d1, v1, d_o, v_o, switch + " default")
     assert any(n.startswith("stem_h3") for n in names) and any(n.startswith("up_h3") for n in names)
+    assert any(n.startswith("conv_h3w") for n in names)          # the conv_0 layers of the blocks run on the Winograd-z kernel
     assert rel_l2(d1, d) <= 2e-6 and rel_l2(v1, v) <= 5e-6
 
 

@@ -1,0 +1,47 @@
+"""CPU pins of the arithmetic behind conv_h3w_kernel (csrc/nbe_kernels_wino.h), emulated in NumPy (tools/wino_emulation.py):
+the F(2,3) identity along z with the two-phase accumulation order and the negated U3, the 2^14 weight scale with an
+unscaled lo part, and the 2^-11 of the lo(x) product on the weight operand -- held to the float32 tolerances of the GPU
+layer tests (tests/test_gpu_layers.py) against an exact float64 convolution."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import wino_emulation as W          # noqa: E402
+
+
+def _case(cin, cout, dims, seed):
+    rng = np.random.default_rng(seed)
+    x = W.f32(rng.standard_normal((cin,) + dims))
+    w = W.f32(W.unit_rows(rng.standard_normal((cout, cin, 3, 3, 3))))
+    return x, w
+
+
+def test_winograd_z_form_is_exact_in_float64():
+    """With exact arithmetic the form is the convolution (identity, stage order, signs): checked with the weights left in
+    float64 and activations that are exactly representable in f16 (so that the hi / lo split is exact)."""
+    rng = np.random.default_rng(1)
+    x = rng.integers(-8, 9, size=(16, 6, 5, 7)).astype(np.float64)
+    w = rng.integers(-4, 5, size=(8, 16, 3, 3, 3)).astype(np.float64) / 64.0
+    assert np.array_equal(W.conv_winograd_z(x, w, S=2.0 ** 6), W.conv_exact(x, w))
+
+
+def test_winograd_z_emulation_meets_the_float32_tolerances():
+    x, w = _case(32, 16, (6, 7, 9), 2)
+    ye = W.conv_exact(x, w)
+    e_w, e_d = W.rel(W.conv_winograd_z(x, w), ye), W.rel(W.conv_f16x3_direct(x, w), ye)
+    assert e_w <= 2e-6 and e_d <= 2e-6, (e_w, e_d)
+    assert e_w <= 4 * e_d + 1e-7, (e_w, e_d)                    # the transform amplifies rounding by a small factor only
+
+
+def test_winograd_z_emulation_follows_the_direct_form_over_the_f16_range():
+    """The transform works on joined float32 values and re-splits them like a producer's epilogue: no fixed-point floor
+    of its own.  (Below ~2^-14 the hi parts themselves go subnormal, for both forms: the range shift of include/nbe.h
+    keeps calls away from there.)"""
+    x, w = _case(16, 8, (4, 5, 6), 3)
+    for s in (2.0 ** -10, 1.0, 2.0 ** 12):
+        xs = W.f32(x * s)
+        ye = W.conv_exact(xs, w)
+        e_w, e_d = W.rel(W.conv_winograd_z(xs, w), ye), W.rel(W.conv_f16x3_direct(xs, w), ye)
+        assert e_w <= 2e-6 and e_w <= 4 * e_d + 1e-7, (s, e_w, e_d)

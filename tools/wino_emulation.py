@@ -1,0 +1,103 @@
+"""NumPy emulation of conv_h3w_kernel's arithmetic (csrc/nbe_kernels_wino.h) against an exact float64 convolution:
+Winograd F(2,3) along z with the two-phase K order (xi = 1 -> A, xi = 2 -> B; butterfly; xi = 0 -> A, xi = 3 -> B with U3
+negated), weights scaled by 2^14 and split into f16 hi + UNSCALED f16 lo, hi * 2^-11 as the weight operand of the lo(x)
+product, activations joined / transformed / re-split in float32, one float32 accumulator per output rounded after every
+16-channel tap product.  Beside it the direct f16x3 form of conv_h3g_kernel (separate main / correction accumulators).
+
+  python tools/wino_emulation.py            # 64 -> 64 channels, prints relative L2 errors at a few input scales
+"""
+import numpy as np
+
+f16 = lambda a: a.astype(np.float16).astype(np.float64)
+f32 = lambda a: a.astype(np.float32).astype(np.float64)
+
+
+def split_scaled(a):
+    hi = f16(a)
+    return hi, f16((a - hi) * 2048.0)
+
+
+def conv_exact(x, w):
+    cout, cin = w.shape[:2]
+    D, H, W = x.shape[1:]
+    y = np.zeros((cout, D - 2, H - 2, W - 2))
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                y += np.einsum('oi,izyx->ozyx', w[:, :, dz, dy, dx], x[:, dz:dz + D - 2, dy:dy + H - 2, dx:dx + W - 2])
+    return y
+
+
+def conv_f16x3_direct(x, w):
+    cout, cin = w.shape[:2]
+    D, H, W = x.shape[1:]
+    Do, Ho, Wo = D - 2, H - 2, W - 2
+    xh, xl = split_scaled(x)
+    wh, wl = split_scaled(w)
+    ym = np.zeros((cout, Do, Ho, Wo))
+    yc = np.zeros_like(ym)
+    for c0 in range(0, cin, 16):
+        for dz in range(3):
+            for dy in range(3):
+                for dx in range(3):
+                    sl = (slice(c0, c0 + 16), slice(dz, dz + Do), slice(dy, dy + Ho), slice(dx, dx + Wo))
+                    Wh, Wl = wh[:, c0:c0 + 16, dz, dy, dx], wl[:, c0:c0 + 16, dz, dy, dx]
+                    ym = f32(ym + np.einsum('oi,izyx->ozyx', Wh, xh[sl]))
+                    yc = f32(yc + np.einsum('oi,izyx->ozyx', Wh, xl[sl]))
+                    yc = f32(yc + np.einsum('oi,izyx->ozyx', Wl, xh[sl]))
+    return f32(ym + yc / 2048.0)
+
+
+def conv_winograd_z(x, w, S=2.0 ** 14):
+    cout, cin = w.shape[:2]
+    D, H, W = x.shape[1:]
+    Do, Ho, Wo = D - 2, H - 2, W - 2
+    assert Do % 2 == 0
+    U = np.stack([w[:, :, 0], (w[:, :, 0] + w[:, :, 1] + w[:, :, 2]) / 2, (w[:, :, 0] - w[:, :, 1] + w[:, :, 2]) / 2,
+                  -w[:, :, 2]], axis=0) * S                       # [xi][o][i][dy][dx], pack_h3w_kernel
+    Uh = f16(U)
+    Ul = f16(U - Uh)                                              # unscaled remainder
+    Uhp = f16(Uh / 2048.0)                                        # v_pk_mul_f16 by 2^-11
+    xj = f32(f16(x) + split_scaled(x)[1] / 2048.0)                # the stored (hi, lo) planes, joined in float32
+    y = np.zeros((cout, Do, Ho, Wo))
+    for p in range(Do // 2):
+        d = [xj[:, 2 * p + k] for k in range(4)]
+        V = [f32(d[0] - d[2]), f32(d[1] + d[2]), f32(d[2] - d[1]), f32(d[1] - d[3])]
+
+        def run(acc, xi):
+            Vh, Vl = split_scaled(V[xi])
+            for c0 in range(0, cin, 16):
+                for dy in range(3):
+                    for dx in range(3):
+                        sl = (slice(c0, c0 + 16), slice(dy, dy + Ho), slice(dx, dx + Wo))
+                        acc = f32(acc + np.einsum('oi,iyx->oyx', Uhp[xi][:, c0:c0 + 16, dy, dx], Vl[sl]))
+                        acc = f32(acc + np.einsum('oi,iyx->oyx', Uh[xi][:, c0:c0 + 16, dy, dx], Vh[sl]))
+                        acc = f32(acc + np.einsum('oi,iyx->oyx', Ul[xi][:, c0:c0 + 16, dy, dx], Vh[sl]))
+            return acc
+        A = run(np.zeros((cout, Ho, Wo)), 1)
+        B = run(np.zeros((cout, Ho, Wo)), 2)
+        A, B = f32(A + B), f32(A - B)
+        A, B = run(A, 0), run(B, 3)
+        y[:, 2 * p], y[:, 2 * p + 1] = f32(A / S), f32(B / S)
+    return y
+
+
+def unit_rows(w):
+    return w / np.sqrt((w ** 2).sum(axis=(1, 2, 3, 4), keepdims=True))
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    cin = cout = 64
+    x = f32(rng.standard_normal((cin, 10, 12, 12)))
+    w = f32(unit_rows(rng.standard_normal((cout, cin, 3, 3, 3))))
+    ye = conv_exact(x, w)
+    print("direct f16x3      rel-L2 %.2e" % rel(conv_f16x3_direct(x, w), ye))
+    print("Winograd-z merged rel-L2 %.2e" % rel(conv_winograd_z(x, w), ye))
+    for s in (1e-3, 30.0, 1e3):
+        xs = f32(x * s)
+        print("  input scale %g: %.2e" % (s, rel(conv_winograd_z(xs, w), conv_exact(xs, w))))
