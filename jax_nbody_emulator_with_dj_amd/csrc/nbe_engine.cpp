@@ -418,7 +418,7 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
     const PackedW& pw = (g6 && L.kind == 0 && narrow_tile(&L)) ? L.pwn : L.pw;
     // Winograd along z (conv_h3w_kernel): gauged wide 3x3x3 launches without a fused skip or residual, on an even number
     // of output planes (the conditions of launch_h3w).  NBE_WINO=0 is the A/B switch (read per launch: tests flip it).
-    cl.wino = g6 && c->wino_ok && &pw == &L.pw && pw.ww && !cl.skw && !(cl.flags & F_RES) && (cl.Dv & 1) == 0 && cl.in_off == 0 &&
+    cl.wino = g6 && c->wino_ok && &pw == &L.pw && pw.ww && (!cl.skw || cl.skw->ww) && !(cl.flags & F_RES) && (cl.Dv & 1) == 0 && cl.in_off == 0 &&
               cl.osz == 1 && !(getenv("NBE_WINO") && atoi(getenv("NBE_WINO")) == 0);
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
@@ -1240,6 +1240,10 @@ static int pack_wino(nbe_ctx* c) {
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
         if (L.pw.ww && L.g6) launch_pack_h3w(L.wn, L.cout, L.cin, L.pw.cin_pad, L.pw.ctiles, L.pw.ww, c->wino_flag, c->stream);
+        if (L.pw.ww && L.kind == 1 && L.b_sub && c->fuse) {        // a fused skip: [W_s | dW_s~] for conv_h3w_kernel<SKIP>
+            launch_pack_h3w_skip(L.wn, L.cout, L.cin, L.pw, L.pw.ww, c->wino_flag, c->stream);
+            launch_pack_h3w_skip(L.dwn, L.cout, L.cin, L.pw, L.pw.ww + L.pw.floats, c->wino_flag, c->stream);
+        }
     }
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, c->wino_flag, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1453,6 +1457,8 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
         // Winograd-z packing (conv_h3w_kernel): 4 transformed kernels per 3 dz slices, wide tile only, Cin <= 128
         if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && !L.first && !L.pwn.w && pw.cin_pad / 16 <= 8)
             HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
+        if (c->prec == PREC_F16X3 && c->vel && L.kind == 1 && !L.pwn.w && pw.cin_pad / 16 <= 8)     // a skip that may run fused: W_s and dW_s~
+            HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 2 * 4));
         // the first layer in its own packing (stem_h3_kernel): K = 27 taps x 3 channels = 81 <= 96
         if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && L.first && d.cin <= 3 && d.cout <= 64)
             HIPCHK(hipMalloc((void**)&pw.stem, 4 * 3 * 4 * 64 * 16));

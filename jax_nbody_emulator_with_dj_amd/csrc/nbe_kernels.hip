@@ -252,6 +252,7 @@ int launch_conv(const PackedW& pw, const ConvLaunch& L, bool vel, bool has_dx, h
     ka.up8 = L.set < 0 ? 1 : 0; ka.set_stride = (long)pw.floats * 4;
     ka.stem_w = pw.stem;
     ka.ww = L.wino ? pw.ww : nullptr;
+    ka.wws = (L.wino && L.skw) ? L.skw->ww : nullptr; ka.wws_set_floats = L.skw ? L.skw->floats : 0;
     ka.w = pw.w + (size_t)set * pw.floats;
     ka.dw = pw.dw ? pw.dw + (size_t)set * pw.floats : nullptr;
     ka.nchunk = pw.cin_pad / prec_ck(pw.prec, pw.mode);

@@ -2141,7 +2141,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
             if (pw.cout_t == 16) return launch_h3g<true, false>(ka, ct, s);
             const bool big = getenv("NBE_H3G_BIG") && atoi(getenv("NBE_H3G_BIG")) == 1;   // A/B switch: 4 x 4 wave tile, one wave per SIMD
             if (big) return launch_h3g<false, false, true>(ka, ct, s);
-            if (ka.ww && launch_h3w(ka, ka.ww, ct, s) == 0) return 0;     // Winograd along z; 1: no such form for this launch
+            if (ka.ww && launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s) == 0) return 0;     // Winograd along z; 1: no such form for this launch
             return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
         }
         return launch_h2q<false, true>(ka, ct, s);
@@ -2180,7 +2180,8 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
 // channel = chunk*16 + 8*h + j; part 0 = hi, 1 = lo * 2^11
 __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ w, int cout, int cin, int kind,
                                                       int mode, int nchunk, long halves_per_set, int nsets,
-                                                      int parts, int cout_t, _Float16* __restrict__ dst) {
+                                                      int parts, int cout_t, _Float16* __restrict__ dst,
+                                                      float wscale = 0.f, int* __restrict__ flag = nullptr) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= halves_per_set * nsets) return;
     const int TAPS = mode_taps(mode), nseg = mode_nseg(mode);
@@ -2206,8 +2207,22 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
     else { k = 2; kz = 1 - ((set >> 2) & 1); ky = 1 - ((set >> 1) & 1); kx = 1 - (set & 1); }
     float v = 0.f;
     if (oc < cout && ci < cin) v = w[(((size_t)oc * cin + ci) * k + kz) * k * k + ky * k + kx];
+    if (wscale != 0.f) {                                         // conv_h3w_kernel's form: value * 2^14, lo = the unscaled remainder
+        v *= wscale;
+        if (!(fabsf(v) <= 60000.f)) { atomicOr(flag, 1); v = 0.f; }
+        const _Float16 h = (_Float16)v;
+        dst[idx] = part == 0 ? h : (_Float16)(v - (float)h);
+        return;
+    }
     const _Float16 hi = (_Float16)v;
     dst[idx] = part == 0 ? hi : (_Float16)((v - (float)hi) * H3_SCALE);
+}
+
+// a fused skip's weights for conv_h3w_kernel: the FLAT1 packing of `pw` with the kernel's 2^14 scale (dst: pw.floats floats)
+void launch_pack_h3w_skip(const float* w_oidhw, int cout, int cin, const PackedW& pw, float* dst, int* flag, hipStream_t s) {
+    const long halves = pw.floats * 2;
+    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((halves + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
+                       1, pw.mode, pw.cin_pad / 16, halves, 1, 2, pw.cout_t, (_Float16*)dst, 16384.0f, flag);
 }
 
 void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s) {

@@ -39,6 +39,7 @@ struct ConvKArgs {
     const float* ws; const float* dws; int nskip;
     long dws_delta;          // dws - ws in bytes
     int up8; long set_stride; // up_h3_kernel: all eight parity sets of an up-sampling layer; bytes between weight sets
+    const float* wws; long wws_set_floats;   // conv_h3w_kernel<SKIP>: the fused skip's [W_s | dW_s~] in that kernel's scaling, floats per set
     const float* ww;         // conv_h3w_kernel: the layer's Winograd-z packed weights when this launch may use them, or NULL
     const float* stem_w;     // stem_h3_kernel: the first layer's weights in its own packing (PackedW::stem), or NULL
     ConvGroupSrc gs[NBE_MAX_GROUPS];

@@ -33,6 +33,7 @@
 // 28 MFMAs per tile where the direct kernel runs 6.
 
 constexpr int NBE_MAX_WSTAGES = 32;                // 4 * Cin / 16: Cin <= 128
+constexpr int NBE_MAX_WSKIP = 16;                  // fused skip: 2 planes x Cin_block / 16 raw stages after the transformed ones
 constexpr float WINO_WSCALE = 16384.0f;            // 2^14
 
 struct WinoSrc { const char* xa; const char* xb; long dxd; const char* w; long psb; float sb; int pad_; };
@@ -43,9 +44,17 @@ struct WinoKArgs {
     float* y; float* dy; long out_pstride; int out_g0;
     const float* bias; const float* gout; const float* beta;
     float inv_scale;
-    WinoSrc st[NBE_MAX_WSTAGES];
+    int nskip;                 // SKIP: 16-channel chunks of the block input (two raw stages each, plane z0 and plane z0 + 1)
+    long dws_delta;            // SKIP: bytes from the scaled W_s to the scaled dW_s~ of a chunk
+    WinoSrc st[NBE_MAX_WSTAGES + NBE_MAX_WSKIP];
 };
 
+// SKIP: the block's 1x1x1 skip runs inside this, its last, convolution as in conv_h3g_kernel: after the transformed stages, two
+// RAW stages per 16-channel chunk of the block input (its plane under z0 into set A, the next one into set B), patches by
+// global -> LDS DMA (nothing to transform), weights [W_s | dW_s~] scaled by 2^14 like the layer's own:
+//     y += W_s.x      dy += W_s.dx~ + dW_s~.x          (dW_s~ = dW_s - W_s (.) a - beta_1 W_s, see conv_h3g_kernel)
+// on the centre tap, the K halves selecting the part: [wh | wh 2^-11] . [xh | xl] and [wl | 0] . [xh | xl].
+template <bool SKIP>
 __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     typedef HGGeom<false, true, false> G;
     constexpr int NW = 8, CT = 64, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = 4, NT = 2, NTILE = 8;
@@ -67,19 +76,36 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     const int nst = 4 * a.nchunk;
 
     const long to = (((long)z0 * a.H + y0) * a.W + x0) * 16;
-    const long wcm = (long)ct * nst * WGU * 16;
+    const long wcm = (long)ct * nst * WGU * 16, wcs = (long)ct * a.nskip * TAPU * 16;
 
     // ---- sources of the stage being prepared
     struct Nxt { const char *xa, *xb, *w0; long dxd, psb; float sb; } nx;
     auto set_next = [&](int s) {
         const WinoSrc e = a.st[s];
-        nx.xa = e.xa + to; nx.xb = e.xb + to; nx.dxd = e.dxd; nx.psb = e.psb; nx.w0 = e.w + wcm; nx.sb = e.sb;
+        nx.xa = e.xa + to; nx.xb = e.xb + to; nx.dxd = e.dxd; nx.psb = e.psb; nx.w0 = e.w + (SKIP && s >= nst ? wcs : wcm); nx.sb = e.sb;
     };
     auto dma_w = [&](int buf, int t) {                           // 36 wave-instructions of weights, 5 slots per wave
         const int n = wave + NW * t;
         unsigned l16 = (unsigned)lane;
         asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(l16));       // recomputed at every use: held in a register it is spilled
         if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, l16, lds + buf * WGU + n * 64);
+    };
+    // ---- a raw stage (SKIP): 8 wave-instructions of weights (W_s, dW_s~ of the chunk: one per wave) and 24 + 24 of the x and
+    // dx~ patches of ONE plane (three + three per wave), straight into the buffers of the stage
+    auto dma_raw = [&](int buf) {
+        unsigned l16 = (unsigned)lane;
+        asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(l16));
+        dma16s(nx.w0 + (wave < 4 ? 0 : a.dws_delta) + (long)(wave & 3) * 1024, l16, lds + buf * WGU + wave * 64);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int tensor = t / 3, n = wave + NW * (t % 3), pl = n / 6, k = n - 6 * pl;
+            const int u = k * 64 + lane;
+            const int uu = u < HP_PL ? u : HP_PL - 1;
+            const int row = (uu * 241) >> 13, col = uu - row * HP_RS;
+            if (u < HP_PL)
+                dma16s(nx.xa + (tensor ? nx.dxd : 0) + (long)pl * nx.psb, (unsigned)(row * a.W + col) * 16u,
+                       lds + XBASE + buf * HQ_XB + tensor * HQ_XT + pl * HQ_PP + k * 64);
+        }
     };
     // ---- the transformed patch of the next stage: 24 wave-items (tensor, channel half, 64 units of the 340) of a hi and a
     // lo plane each, three per wave; an item is four 16-byte loads per lane (a hi, a lo, b hi, b lo), 8 channels of
@@ -272,12 +298,13 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     constexpr int SH4 = HP_RS + 1, SH5 = HP_RS + 2, SH7 = 2 * HP_RS + 1;   // tap shifts: 3*dy + dx -> dy*34 + dx
     // (pxc: a stage follows -- a compile-time constant, so that the fetch of the next stage costs no branches; only the
     // last stage of a workgroup runs the other instantiation)
-    auto stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s, auto pxc) {
-        constexpr bool px = decltype(pxc)::value;
+    auto stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s, auto nxt) {
+        constexpr int NXT = decltype(nxt)::value;                // what follows: 0 nothing, 1 a transformed stage, 2 a raw stage (SKIP)
+        constexpr bool px = NXT == 1;
         // the first operands of stage s+1 are requested under the last products of stage s -- except across the phase
         // boundary, where they would only be carried through the butterfly (registers): it requests them itself
         const bool pre = px && s + 1 != 2 * a.nchunk;
-        if (px) set_next(s + 1);
+        if (NXT) set_next(s + 1);
         // (the buffer parity is a compile-time constant of each instantiation: hidden from the compiler, which would
         // otherwise precompute one address register per LDS read of the stage -- dozens, spilled)
         int par = s & 1;
@@ -292,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         Xf xf;
         auto hk = [&](int k) { xf_step(g, xf, k); };
         auto none = [] {};
+        if (NXT == 2) dma_raw(nb);                               // (its first operands are requested by the raw stage itself)
         if (px) st_load(0, g);
         pair(Y, DY, 0, nb, px, wb, xb + bP1,                                              // taps (0,1) + the weight DMA of stage s+1
              [&] { LB(xl, xb + 2 + bP32 + HQ_PP); }, [&] { LA(wh, wb + 2 * TAPU + aP); }, [&] { LB(xh, xb + 2 + bP32); },
@@ -328,6 +356,40 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
              [&] { if (pre) LB(xl, xbn + bP1 + HQ_PP); }, [&] { if (pre) LA(wh, wbn + aP); }, [&] { if (pre) LB(xh, xbn + bP1); },
              [&] { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); },
              px, hk, [&] { if (px) st_write(2, nb, xf); });
+    };
+
+    // ---- a raw stage of the fused skip: six products on the centre tap of the block input's patch
+    auto raw_stage = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int s, bool px) {
+        if (px) set_next(s + 1);
+        int par = s & 1;
+        asm volatile("" : "+s"(par));
+        int nb = 1 - par;
+        asm volatile("" : "+s"(nb));
+        const int wb = par * WGU, xb = XBASE + par * HQ_XB;
+        if (px) dma_raw(nb);
+        half8 a1[MT], a2[MT], d1[MT], d2[MT], bx[NT], bd[NT];
+        const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const _Float16 m1 = ks ? kInv : (_Float16)1.0f;
+        const int aS = wb + (2 * kh) * CT + c;
+        const int bS = xb + (2 * kh + ks) * HQ_PP + rowp * HP_RS + c + SH4;
+        LA(a1, aS); LB(bx, bS); LA(a2, aS + CT); LB(bd, bS + HQ_XT);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a1[mt] = a1[mt] * m1;
+        NBE_SB; MM8(Y, a1, bx, -1, 0, false, true); NBE_SB;                               // [W_s hi | W_s hi 2^-11] . [x hi | x lo]
+        LA(d1, aS + TAPU);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a2[mt] = ks ? zero : a2[mt];
+        NBE_SB; MM8(Y, a2, bx, -1, 0, false, true); NBE_SB;                               // [W_s lo | 0] . [x hi | x lo]
+        LA(d2, aS + TAPU + CT);
+        if (!(a.flags & F_SKIP_NODX)) {                                                  // (conv_l00: the input field has no tangent)
+            NBE_SB; MM8(DY, a1, bd, -1, 0, false); NBE_SB;
+            MM8(DY, a2, bd, -1, 0, false); NBE_SB;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { d1[mt] = d1[mt] * m1; d2[mt] = ks ? zero : d2[mt]; }
+        NBE_SB; MM8(DY, d1, bx, -1, 0, false, true); NBE_SB;                              // dW_s~ . x
+        MM8(DY, d2, bx, -1, 0, false, true); NBE_SB;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
     // ---- prologue: stage 0
@@ -373,14 +435,20 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #ifndef WX_NOBF
         if (s2 == a.nchunk) butterfly();
 #endif
-        stage(YA, DA, 2 * s2, std::true_type());
-        stage(YB, DB, 2 * s2 + 1, std::true_type());
+        stage(YA, DA, 2 * s2, std::integral_constant<int, 1>());
+        stage(YB, DB, 2 * s2 + 1, std::integral_constant<int, 1>());
     }
 #ifndef WX_NOBF
     if (npairs - 1 == a.nchunk) butterfly();
 #endif
-    stage(YA, DA, 2 * npairs - 2, std::true_type());
-    stage(YB, DB, 2 * npairs - 1, std::false_type());
+    stage(YA, DA, 2 * npairs - 2, std::integral_constant<int, 1>());
+    stage(YB, DB, 2 * npairs - 1, std::integral_constant<int, SKIP ? 2 : 0>());
+    if (SKIP) {
+        for (int sc = 0; sc < a.nskip; ++sc) {
+            raw_stage(YA, DA, nst + 2 * sc, true);
+            raw_stage(YB, DB, nst + 2 * sc + 1, sc + 1 < a.nskip);
+        }
+    }
 #undef NBE_SB
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
 
@@ -482,16 +550,19 @@ void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int c
 }
 
 // 0: launched; 1: this launch has no Winograd form (the caller falls back to conv_h3g_kernel)
-static int launch_h3w(const ConvKArgs& ka, const float* ww, int ctiles, hipStream_t s) {
+// wws: the fused skip's weights [W_s | dW_s~] in the kernel's scaling (PackedW::ww of the skip layer), needed when ka.nskip > 0
+static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, long wws_set_floats, int ctiles, hipStream_t s) {
     typedef HGGeom<false, true, false> G;
     constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
-    if (!ww || ka.nskip > 0 || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || !ka.beta) return 1;
+    if (!ww || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || !ka.beta) return 1;
+    if (ka.nskip > 0 && (!wws || 2 * ka.nskip > NBE_MAX_WSKIP)) return 1;
     if (ctiles != (ka.cout_groups + 7) / 8) return 1;
     // the raw planes are fetched with buffer loads: lane offset + hi -> lo plane distance must stay below 2^31
     if (std::max(ka.in_pstride, ka.csplit < ka.nchunk ? ka.in2_pstride : 0L) * 16 + 16L * (HP_ROWS + 2) * ka.W >= (1L << 31)) return 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     WinoKArgs wa;
@@ -503,6 +574,7 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, int ctiles, hipStrea
     wa.y = ka.y; wa.dy = ka.dy; wa.out_pstride = ka.out_pstride; wa.out_g0 = ka.out_g0;
     wa.bias = ka.bias; wa.gout = ka.gout; wa.beta = ka.beta;
     wa.inv_scale = 1.0f / WINO_WSCALE;
+    wa.nskip = ka.nskip; wa.dws_delta = wws_set_floats * 4;
     // stage order: phase 0 = (xi 1 -> A, xi 2 -> B) per chunk, phase 1 = (xi 0 -> A, xi 3 -> B) per chunk
     static const int XI[2][2] = {{1, 2}, {0, 3}};
     static const int PA[4] = {0, 1, 2, 1}, PB[4] = {2, 2, 1, 3};
@@ -521,7 +593,20 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, int ctiles, hipStrea
                 e.xa = x + off + PA[xi] * plane; e.xb = x + off + PB[xi] * plane; e.dxd = dx - x;
                 e.w = (const char*)ww + (long)(chunk * 4 + xi) * G::WG * 16; e.psb = ps * 16; e.sb = SB[xi]; e.pad_ = 0;
             }
+    // raw stages of the fused skip: chunk sc of the block input, plane z0 (-> A) and plane z0 + 1 (-> B); ka.xs is already
+    // offset so that the centre tap of the patch of output tile (z, y0, x0) is the skip's voxel
+    for (int sc = 0; sc < ka.nskip; ++sc)
+        for (int ab = 0; ab < 2; ++ab) {
+            const bool second = sc >= ka.s_csplit;
+            const long ps = second ? ka.s2_pstride : ka.s_pstride;
+            const char* x = (const char*)(second ? ka.xs2 : ka.xs);
+            const char* dx = (const char*)(second ? ka.dxs2 : ka.dxs);
+            const long off = (long)(second ? sc - ka.s_csplit : sc) * 4 * ps * 16 + ab * plane;
+            WinoSrc& e = wa.st[4 * ka.nchunk + 2 * sc + ab];
+            e.xa = x + off; e.xb = e.xa; e.dxd = dx - x; e.w = (const char*)wws + (long)sc * G::TAPU * 16; e.psb = ps * 16; e.sb = 0.f; e.pad_ = 0;
+        }
     dim3 grid(wa.ntiles * ctiles, 1, 1), block(512, 1, 1);
-    hipLaunchKernelGGL(conv_h3w_kernel, grid, block, smem, s, wa);
+    if (ka.nskip > 0) hipLaunchKernelGGL(conv_h3w_kernel<true>, grid, block, smem, s, wa);
+    else hipLaunchKernelGGL(conv_h3w_kernel<false>, grid, block, smem, s, wa);
     return 0;
 }
