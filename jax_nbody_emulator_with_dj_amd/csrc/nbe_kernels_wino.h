@@ -140,9 +140,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         // buffer loads: wave-uniform base in a resource descriptor (SGPRs) + 32-bit lane offset (+ the lo plane's distance as
         // the scalar offset) -- the compiler's own global loads keep a 64-bit address per lane and load.  Unlike loads
         // issued from asm statements these are visible to the compiler's vmcnt bookkeeping (spill-safe, counted waits).
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, 0x7fffffff, 0x00027000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0x7fffffff, 0x00027000);
-        const unsigned pso = (unsigned)nx.psb;                   // < 2^31 - patch extent: checked by the launcher
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, 0xffffffffu, 0x00027000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, 0xffffffffu, 0x00027000);
+        const unsigned pso = (unsigned)nx.psb;                   // < 2^32 - patch extent: checked by the launcher
         auto ld = [&](half8& d, __amdgpu_buffer_rsrc_t r, unsigned so) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, go, so, 0);
             d = __builtin_bit_cast(half8, v);
@@ -557,8 +557,8 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
     if (!ww || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || !ka.beta) return 1;
     if (ka.nskip > 0 && (!wws || 2 * ka.nskip > NBE_MAX_WSKIP)) return 1;
     if (ctiles != (ka.cout_groups + 7) / 8) return 1;
-    // the raw planes are fetched with buffer loads: lane offset + hi -> lo plane distance must stay below 2^31
-    if (std::max(ka.in_pstride, ka.csplit < ka.nchunk ? ka.in2_pstride : 0L) * 16 + 16L * (HP_ROWS + 2) * ka.W >= (1L << 31)) return 1;
+    // the raw planes are fetched with buffer loads (32-bit offsets): lane offset + hi -> lo plane distance stay below 2^32
+    if (std::max(ka.in_pstride, ka.csplit < ka.nchunk ? ka.in2_pstride : 0L) * 16 + 16L * (HP_ROWS + 2) * ka.W >= (1L << 32) - (1L << 20)) return 1;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
