@@ -286,8 +286,10 @@ def main():
         }
         if prof:
             out["roofline"] = roofline(prof, args.precision, plan)
-            if out["roofline"]["kernel"].startswith("conv_h3w"):      # the direct gauged kernel (blocks' conv_1 + fused skips) beside it
-                out["roofline_direct_kernel"] = roofline(prof, args.precision, plan, kernel="conv_h3g")
+            if out["roofline"]["kernel"].startswith("conv_h3w"):      # launches that fell back to the direct gauged kernel, if any
+                rd = roofline(prof, args.precision, plan, kernel="conv_h3g")
+                if rd is not None:
+                    out["roofline_direct_kernel"] = rd
             out["kernels"] = [{"kernel": e["kernel"], "ms": round(e["ms"], 3), "launches": e["launches"],
                                "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 2) if e["ms"] > 0 else None}
                               for e in sorted(prof, key=lambda e: -e["ms"])]
