@@ -422,7 +422,10 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
               cl.osz == 1 && !(getenv("NBE_WINO") && atoi(getenv("NBE_WINO")) == 0);
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
-        pe = prof_entry(c, cl.wino ? std::string("conv_h3w<FLAT3,vel,dx>") : conv_name(pw, c->vel, has_dx, g6, cl.set < 0));
+        std::string pn = cl.wino ? std::string("conv_h3w<FLAT3,vel,dx>") : conv_name(pw, c->vel, has_dx, g6, cl.set < 0);
+        static const bool per_layer = getenv("NBE_PROF_LAYERS") && atoi(getenv("NBE_PROF_LAYERS")) == 1;   // tools: one entry per layer
+        if (per_layer) pn += " " + L.block + "/" + L.layer;
+        pe = prof_entry(c, pn);
         ea = get_event(c); eb = get_event(c);
         (void)hipEventRecord(ea, c->stream);
     }

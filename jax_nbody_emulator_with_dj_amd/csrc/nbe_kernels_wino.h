@@ -67,6 +67,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
 
     const int nct = (a.cout_groups + 7) / 8;
+    // (persistent workgroups looping over tiles -- grids of 256, 512, 1024 -- were measured: +-0.3 % per box; what a tile
+    // spends outside its stages, ~4.5 stage times, is its own epilogue, butterfly and first staging, not the dispatch)
     const int vt = xcd_tile(blockIdx.x, a.ntiles * nct);
     const int tile = vt / nct, ct = vt - tile * nct;
     const int npair = a.Dv >> 1;
@@ -400,8 +402,12 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         set_next(0);
 #pragma unroll
         for (int k = 0; k < G::NWS; ++k) dma_w(0, k);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { Stg g; st_load(j, g); st_store(j, 0, g); }
+        {
+            // all three items in flight at once (nothing else is live yet): one memory latency exposed instead of three
+            Stg g0, g1, g2;
+            st_load(0, g0); st_load(1, g1); st_load(2, g2);
+            st_store(0, 0, g0); st_store(1, 0, g1); st_store(2, 0, g2);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         LA(wh, aP); LB(xl, XBASE + bP1 + HQ_PP); LB(xh, XBASE + bP1);
@@ -453,8 +459,29 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
 
     // ---- epilogue: y = W.x / 2^14 + b, dy = W.dx~ / 2^14 + beta * (W.x), LeakyReLU (+ tangent), gauge, split, store
+    // The per-channel vectors of the four row tiles are loaded ONCE, before anything is stored, and serve both planes: vmcnt
+    // counts loads and stores alike, so a load among the stores waits for every store issued before it -- with the vectors
+    // fetched per row tile the epilogue was eight rounds of (store, drain, load, wait): 11-26 % of a launch by a timing probe
+    // (a build without the epilogue), one or two stage times per workgroup with the matrix pipe idle.
+    const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
+    f32x4 bv[MT], be[MT], gv[MT];
+    int unit[MT];
+    bool uok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        unit[mt] = ct * (CT / 8) + 2 * mt + ks;
+        uok[mt] = unit[mt] < a.cout_groups;
+        if (!uok[mt]) unit[mt] = a.cout_groups - 1;
+        bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
+        be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
+        gv[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
+    }
+    // (a use of all of them here: the compiler waits for the loads now, once -- left to their first uses it waits with a count
+    // that only the draining of the stores issued in between can satisfy)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(bv[mt]), "+v"(be[mt]), "+v"(gv[mt]));
     auto epilogue = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int z) {
-        const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
         int o[NT];
         bool ook[NT];
 #pragma unroll
@@ -465,13 +492,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            int unit = ct * (CT / 8) + 2 * mt + ks;
-            const bool uok = unit < a.cout_groups;
-            if (!uok) unit = a.cout_groups - 1;
-            const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * kh);
-            const f32x4 be = *(const f32x4*)(a.beta + unit * 8 + 4 * kh);
-            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-            if (gauge) gv = *(const f32x4*)(a.gout + unit * 8 + 4 * kh);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int t = mt * NT + nt;
@@ -480,8 +500,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float yp = acc_read(Y[t][e]) * a.inv_scale;
-                    v[e] = yp + bv[e];
-                    dv[e] = acc_read(DY[t][e]) * a.inv_scale + be[e] * yp;
+                    v[e] = yp + bv[mt][e];
+                    dv[e] = acc_read(DY[t][e]) * a.inv_scale + be[mt][e] * yp;
                 }
                 if (act) {
 #pragma unroll
@@ -492,10 +512,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
                 }
                 if (gauge) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dv[e] += gv[e] * v[e];
+                    for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
                 }
-                if (uok && ook[nt]) {
-                    const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
+                if (uok[mt] && ook[nt]) {
+                    const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
                     const long ol = ob + a.out_pstride * 16;
                     half4 hi, lo;
                     split4(v, hi, lo);
@@ -508,8 +528,12 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             }
         }
     };
+#ifdef WX_NOEPI
+    if (a.Dv < 0) { epilogue(YA, DA, z0); epilogue(YB, DB, z0 + 1); }        // timing probe: no epilogue (results invalid)
+#else
     epilogue(YA, DA, z0);
     epilogue(YB, DB, z0 + 1);
+#endif
 }
 
 // Winograd packing of a 3x3x3 layer's weights (OIDHW float32) for conv_h3w_kernel:
