@@ -1937,7 +1937,8 @@ constexpr int ST_PL = (ST_ROWS + 2) * HP_RS;                 // halves of one (p
 constexpr int ST_PV = 3 * ST_PL;                             // patch voxels of a tile: 612
 constexpr int ST_PATCH = 3680;                               // 2 parts x 3 channels x 3 dz planes = 3672 halves, rounded to 16 B
 constexpr int ST_WU = 4 * 3 * 4 * 64;                        // weight units: [set 4][k-step 3][k-block 4][64 couts] x 8 halves
-constexpr size_t ST_LDS = (size_t)ST_WU * 16 + 2 * ST_PATCH * 2;   // 63,872 B: two workgroups per CU
+constexpr int ST_VEC = ST_WU * 4 + ST_PATCH;                  // floats: after the two patch buffers, bias[64] and gout[64]
+constexpr size_t ST_LDS = (size_t)ST_WU * 16 + 2 * ST_PATCH * 2 + 2 * 64 * 4;   // 64,384 B: two workgroups per CU
 
 __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
     f32x4* lds = lds_h3;
@@ -2000,9 +2001,14 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 
     int tile = blockIdx.x;
     if (tile < ntiles) fetch(tile);
+    const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
+    // the per-channel vectors live in LDS for the life of the (persistent) workgroup: fetched from memory inside the
+    // epilogue, each load waits for the stores issued before it (vmcnt counts both) -- four store drains per tile
+    float* Lvec = (float*)lds_h3 + ST_VEC;
+    if (tid < 64) Lvec[tid] = tid < 8 * a.cout_groups ? a.bias[tid] : 0.f;
+    else if (tid < 128) Lvec[tid] = (gauge && tid - 64 < 8 * a.cout_groups) ? a.gout[tid - 64] : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the weights (and the first patch)
     const int rb = wave * HP_RS + c;
-    const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
         stage(buf);
@@ -2056,9 +2062,8 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
             int unit = 2 * mt + ks;
             const bool uok = unit < a.cout_groups;
             if (!uok) unit = a.cout_groups - 1;
-            const f32x4 bv = *(const f32x4*)(a.bias + unit * 8 + 4 * kh);
-            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-            if (gauge) gv = *(const f32x4*)(a.gout + unit * 8 + 4 * kh);
+            const f32x4 bv = *(const f32x4*)(Lvec + unit * 8 + 4 * kh);
+            const f32x4 gv = *(const f32x4*)(Lvec + 64 + unit * 8 + 4 * kh);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int t = 2 * mt + nt;

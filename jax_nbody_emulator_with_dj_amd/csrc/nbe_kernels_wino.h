@@ -346,6 +346,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a2[mt] = ks ? zero : a2[mt];
+        // (transforming item 1 under the single tap's last products instead, 7 / 5 / 7 products between loads and first use
+        // rather than 6 / 8 / 4, was measured: +-0: the loads' latency is not exposed)
         NBE_SB; MM8(Y, a2, b1x, -1, 0, false, true); NBE_SB;
         MM8(DY, a2, b1d, -1, 0, false); NBE_SB;
         pair(Y, DY, -1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                           // taps (5,6)
