@@ -606,6 +606,8 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
     static const int PA[4] = {0, 1, 2, 1}, PB[4] = {2, 2, 1, 3};
     static const float SB[4] = {-1.f, 1.f, -1.f, -1.f};
     const long plane = (long)ka.H * ka.W * 16;
+    // (walking the chunks backwards in phase 1, so that the planes phase 0 fetched last are fetched again first, was measured:
+    // +-0.1 %)
     for (int ph = 0; ph < 2; ++ph)
         for (int chunk = 0; chunk < ka.nchunk; ++chunk)
             for (int ab = 0; ab < 2; ++ab) {
