@@ -122,7 +122,11 @@ int nbe_load_premod_weights(nbe_ctx* ctx, const nbe_layer_desc* layers, int nlay
  * With velocity (f32 / f16x3) the tangent of style_layers_vel.py:98-105, dy = W.dx + dW.x, is evaluated as
  * W.(dx + alpha x) + beta (W.x) using dW = W (.) (alpha[cin] + beta[cout]) of the style modulation (two contractions
  * per 3x3x3 layer instead of three; same result within rounding).  env NBE_GAUGE=0 at load time keeps the
- * three-product form; a style factor that is exactly zero at (Om, Dz) selects it for that cosmology. */
+ * three-product form; a style factor that is exactly zero at (Om, Dz) selects it for that cosmology.
+ * f16x3 with velocity: the wide 3x3x3 layers run a Winograd F(2,3) transform along z (conv_h3w_kernel: four plane-wise
+ * convolutions per two output planes instead of six, same float32 tolerances).  Its rounding depends on how a launch pairs
+ * its planes, so fields of different tilings / slab plans / rank counts agree to float32 rounding, not bit for bit;
+ * env NBE_WINO=0 (read per launch) selects the direct kernel, whose rounding is independent of the schedule. */
 int nbe_set_cosmology(nbe_ctx* ctx, float Om, float Dz);
 
 /* model.apply(params, x[None], Om, Dz, vel_fac) for ONE batch element
