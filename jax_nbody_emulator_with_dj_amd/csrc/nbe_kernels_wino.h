@@ -41,6 +41,7 @@ struct WinoSrc { const char* xa; const char* xb; long dxd; const char* w; long p
 struct WinoKArgs {
     int H, W, Dv, Hv, Wv, Ho, Wo;
     int nchunk, cout_groups, flags, ntiles, tny, tnx;
+    int zblock;                // tile order: plane pairs fastest in blocks of this many (>= 1)
     float* y; float* dy; long out_pstride; int out_g0;
     const float* bias; const float* gout; const float* beta;
     float inv_scale;
@@ -72,8 +73,23 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     const int vt = xcd_tile(blockIdx.x, a.ntiles * nct);
     const int tile = vt / nct, ct = vt - tile * nct;
     const int npair = a.Dv >> 1;
-    const int zp = tile % npair, tyx = tile / npair;
-    const int ty = tyx / a.tnx, tx = tyx - ty * a.tnx;
+    // tile order: plane pairs fastest in blocks of a.zblock (then x, y, the next block of pairs): the workgroups running side
+    // by side on an XCD share input planes through its L2 along z and pages (TLB reach, of the stores above all) along x
+    int zp, ty, tx;
+    {
+        const int zb = a.zblock;
+        const int full = (npair / zb) * zb;                      // plane pairs in whole blocks
+        const int per_blk = zb * a.tny * a.tnx;
+        if (tile < (npair / zb) * per_blk) {
+            const int blk = tile / per_blk, r = tile - blk * per_blk;
+            const int zi = r % zb, tyx = r / zb;
+            zp = blk * zb + zi; ty = tyx / a.tnx; tx = tyx - ty * a.tnx;
+        } else {                                                 // the remaining pairs: z fastest
+            const int r = tile - (npair / zb) * per_blk, rem = npair - full;
+            const int zi = r % rem, tyx = r / rem;
+            zp = full + zi; ty = tyx / a.tnx; tx = tyx - ty * a.tnx;
+        }
+    }
     const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS, z0 = 2 * zp;
     const int nst = 4 * a.nchunk;
 
@@ -516,16 +532,28 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
                 }
+#ifdef WX_NOSTORE
+                if (uok[mt] && ook[nt] && a.Dv < 0) {        // timing probe: the epilogue's arithmetic without its stores
+#else
                 if (uok[mt] && ook[nt]) {
+#endif
                     const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
                     const long ol = ob + a.out_pstride * 16;
                     half4 hi, lo;
                     split4(v, hi, lo);
+#ifdef WX_NTSTORE
+                    __builtin_nontemporal_store(hi, (half4*)((char*)a.y + ob));
+                    __builtin_nontemporal_store(lo, (half4*)((char*)a.y + ol));
+                    split4(dv, hi, lo);
+                    __builtin_nontemporal_store(hi, (half4*)((char*)a.dy + ob));
+                    __builtin_nontemporal_store(lo, (half4*)((char*)a.dy + ol));
+#else
                     *(half4*)((char*)a.y + ob) = hi;
                     *(half4*)((char*)a.y + ol) = lo;
                     split4(dv, hi, lo);
                     *(half4*)((char*)a.dy + ob) = hi;
                     *(half4*)((char*)a.dy + ol) = lo;
+#endif
                 }
             }
         }
@@ -600,6 +628,12 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
     wa.y = ka.y; wa.dy = ka.dy; wa.out_pstride = ka.out_pstride; wa.out_g0 = ka.out_g0;
     wa.bias = ka.bias; wa.gout = ka.gout; wa.beta = ka.beta;
     wa.inv_scale = 1.0f / WINO_WSCALE;
+    {
+        // A/B (profiles/r02_ab_wino_zblock.txt): 0 = all pairs of the launch (z fastest) 1494 ms per box, 1 (x fastest) 1496,
+        // 2 / 4 / 8 / 16: 1479 / 1481 / 1477 / 1482
+        static const int zb = getenv("NBE_WINO_ZBLOCK") ? atoi(getenv("NBE_WINO_ZBLOCK")) : 8;
+        wa.zblock = zb > 0 ? std::min(zb, ka.Dv / 2) : ka.Dv / 2;
+    }
     wa.nskip = ka.nskip; wa.dws_delta = wws_set_floats * 4;
     // stage order: phase 0 = (xi 1 -> A, xi 2 -> B) per chunk, phase 1 = (xi 0 -> A, xi 3 -> B) per chunk
     static const int XI[2][2] = {{1, 2}, {0, 3}};
