@@ -479,8 +479,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // ---- epilogue: y = W.x / 2^14 + b, dy = W.dx~ / 2^14 + beta * (W.x), LeakyReLU (+ tangent), gauge, split, store
     // The per-channel vectors of the four row tiles are loaded ONCE, before anything is stored, and serve both planes: vmcnt
     // counts loads and stores alike, so a load among the stores waits for every store issued before it -- with the vectors
-    // fetched per row tile the epilogue was eight rounds of (store, drain, load, wait): 11-26 % of a launch by a timing probe
-    // (a build without the epilogue), one or two stage times per workgroup with the matrix pipe idle.
+    // fetched per row tile the epilogue was eight rounds of (store, drain, load, wait); worth 2 % on the 64-channel layers.
+    // (Builds without the stores, or without the epilogue, run a box 13-16 % faster -- but they leave every activation at the
+    // workspace's zeros, and on this power-limited chip MFMAs on zeros are cheap: such probes price the data, not the stores.)
     const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
     f32x4 bv[MT], be[MT], gv[MT];
     int unit[MT];
