@@ -259,17 +259,25 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     };
     const _Float16 kInv = (_Float16)H3_INV;
     // one product on the wave tile; slot >= 0: weight-DMA slots `slot`, `slot + 1` after the two halves of the product
+    // The eight tiles of a product are walked in a snake -- (m0,n0) (m0,n1) (m1,n1) (m1,n0) (m2,n0) ... -- so that consecutive
+    // MFMAs share an operand: eight operand changes per product instead of twelve (this kernel's time is its energy)
+#ifdef WX_NOSNAKE
+#define SNAKE(i) (i)
+#else
+#define SNAKE(i) ((((i) >> 1) & 1) ? ((i) ^ 1) : (i))
+#endif
     auto nohook = [](int) {};
     // (hook(t) runs after MFMA t: a micro-step of VALU work that issues while the matrix pipe is busy with that MFMA)
     auto MM8h = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px, bool zsel,
                     bool hooked, auto&& hook) {
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) {
-            if (zsel && (t % NT) == 0) mmz(acc[t], A[t / NT], B[t % NT]); else
+        for (int i = 0; i < NTILE; ++i) {
+            const int t = SNAKE(i);
+            if (zsel && (i % NT) == 0) mmz(acc[t], A[t / NT], B[t % NT]); else
             mm(acc[t], A[t / NT], B[t % NT]);
-            if (hooked) { hook(t); __builtin_amdgcn_sched_barrier(0); }
-            if (slot >= 0 && (t % 4) == 3) {
-                if (px) dma_w(nb, slot + t / 4);
+            if (hooked) { hook(i); __builtin_amdgcn_sched_barrier(0); }
+            if (slot >= 0 && (i % 4) == 3) {
+                if (px) dma_w(nb, slot + i / 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -282,11 +290,12 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     auto MM8s = [&](f32x4 (&acc)[NTILE], half8 (&P)[MT], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px) {
         P[0] = A[0] * kInv;
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) {
-            if ((t % NT) == 0) { if (t / NT + 1 < MT) P[t / NT + 1] = A[t / NT + 1] * kInv; mmz(acc[t], P[t / NT], B[t % NT]); }
+        for (int i = 0; i < NTILE; ++i) {
+            const int t = SNAKE(i);
+            if ((i % NT) == 0) { if (t / NT + 1 < MT) P[t / NT + 1] = A[t / NT + 1] * kInv; mmz(acc[t], P[t / NT], B[t % NT]); }
             else mm(acc[t], P[t / NT], B[t % NT]);
-            if (slot >= 0 && (t % 4) == 3) {
-                if (px) dma_w(nb, slot + t / 4);
+            if (slot >= 0 && (i % 4) == 3) {
+                if (px) dma_w(nb, slot + i / 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -474,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         }
     }
 #undef NBE_SB
+#undef SNAKE
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // MFMA results -> VALU reads of the epilogue
 
     // ---- epilogue: y = W.x / 2^14 + b, dy = W.dx~ / 2^14 + beta * (W.x), LeakyReLU (+ tangent), gauge, split, store
