@@ -216,7 +216,11 @@ def main():
                    "conv_h3w": "conv_h3w_kernel", "conv_mfma_g": "conv_mfma_kernel"}
             key = next((v for k, v in sub.items() if dom["kernel"].startswith(k)), None)
             if tj.get("build") == _lib.source_hash() and tj.get("workload") == wl and key and world == 1:
-                traffic = next((v["traffic_bytes"] for k, v in tj["kernels"].items() if key in k), None)
+                # (a profile entry may cover several instantiations of a kernel -- conv_h3w_kernel<false> / <true>: the
+                # launch-weighted mean over all that match)
+                m = [v for k, v in tj["kernels"].items() if key in k]
+                if m:
+                    traffic = sum(v["traffic_bytes"] * v["launches"] for v in m) / sum(v["launches"] for v in m)
         except Exception:
             traffic = None
         mpp = {"f32": 1.0, "f16x3": 3.0, "f16": 1.0}[precision] * (2.0 / 3.0 if dom["kernel"].startswith("conv_h3w") else 1.0)
