@@ -131,9 +131,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // (per-lane offsets are recomputed at every use -- a dozen VALU operations per item -- instead of held in registers)
     auto item_unit = [&](int j, bool& valid) {                   // unit 0..339 of the 10 x 34 patch plane this lane handles in item j
         int l = lane;
-#ifndef WX_HOIST
         asm volatile("" : "+v"(l));                              // (or the compiler hoists the offsets out of the loop and spills them)
-#endif
         const int u = ((wave + NW * j) % 6) * 64 + l;
         valid = u < HP_PL;
         return valid ? u : HP_PL - 1;
@@ -146,9 +144,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // (the staging registers belong to one stage: declared there, so that nothing is carried across stage boundaries)
     struct Stg { half8 ah, al, bh, bl; float sb; };
     auto st_load = [&](int j, Stg& g) {
-#ifdef WX_NOST
-        return;
-#endif
         const int n = wave + NW * j;
         const long po = ((n / 12) ? nx.dxd : 0) + (long)(((n % 12) / 6) * 2) * nx.psb;
         const char* pa = nx.xa + po;
@@ -165,18 +160,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, go, so, 0);
             d = __builtin_bit_cast(half8, v);
         };
-#ifdef WX_NOLD
-        asm volatile("" : "=v"(g.ah), "=v"(g.al), "=v"(g.bh), "=v"(g.bl) : "v"(go), "s"(pa), "s"(pb));
-#else
-#ifdef WX_ASMLD
-        auto lda = [&](half8& d, const char* base) {
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(go), "s"(base) : "memory");
-        };
-        lda(g.ah, pa); lda(g.al, pa + nx.psb); lda(g.bh, pb); lda(g.bl, pb + nx.psb);
-#else
         ld(g.ah, ra, 0); ld(g.al, ra, pso); ld(g.bh, rb, 0); ld(g.bl, rb, pso);
-#endif
-#endif
         g.sb = nx.sb;
     };
     // V = (a hi + 2^-11 a lo) + sb (b hi + 2^-11 b lo) on two channels per register with the mixed-precision FMA (f16
@@ -187,9 +171,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // its SIMD for its whole length (measured: 3.2 VALU per MFMA and 56 % matrix-busy with the transform in blocks).
     struct Xf { u32x4 HI, LO; float t0, t1; unsigned h; };
     auto xf_step = [&](const Stg& g, Xf& x, int k) {
-#ifdef WX_NOST
-        return;
-#endif
         const int r = k >> 2, m = k & 3;
         const unsigned AH = __builtin_bit_cast(u32x4, g.ah)[r], AL = __builtin_bit_cast(u32x4, g.al)[r];
         const unsigned BH = __builtin_bit_cast(u32x4, g.bh)[r], BL = __builtin_bit_cast(u32x4, g.bl)[r];
@@ -214,9 +195,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         }
     };
     auto st_write = [&](int j, int buf, const Xf& x) {
-#ifdef WX_NOST
-        return;
-#endif
         bool valid;
         const int n = wave + NW * j;
         const int lo_ = XBASE + buf * HQ_XB + (n / 12) * HQ_XT + (((n % 12) / 6) * 2) * HQ_PP + item_unit(j, valid);
@@ -261,11 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // one product on the wave tile; slot >= 0: weight-DMA slots `slot`, `slot + 1` after the two halves of the product
     // The eight tiles of a product are walked in a snake -- (m0,n0) (m0,n1) (m1,n1) (m1,n0) (m2,n0) ... -- so that consecutive
     // MFMAs share an operand: eight operand changes per product instead of twelve (this kernel's time is its energy)
-#ifdef WX_NOSNAKE
-#define SNAKE(i) (i)
-#else
 #define SNAKE(i) ((((i) >> 1) & 1) ? ((i) ^ 1) : (i))
-#endif
     auto nohook = [](int) {};
     // (hook(t) runs after MFMA t: a micro-step of VALU work that issues while the matrix pipe is busy with that MFMA)
     auto MM8h = [&](f32x4 (&acc)[NTILE], const half8 (&A)[MT], const half8 (&B)[NT], int slot, int nb, bool px, bool zsel,
@@ -423,9 +397,6 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 
     // ---- prologue: stage 0
     {
-#ifdef WX_NOST
-        for (int i = tid; i < 2 * HQ_XB; i += 512) lds[XBASE + i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
         set_next(0);
 #pragma unroll
         for (int k = 0; k < G::NWS; ++k) dma_w(0, k);
@@ -465,15 +436,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // branch between the two instantiations inside the loop would merge two versions of every accumulator
     const int npairs = 2 * a.nchunk;
     for (int s2 = 0; s2 + 1 < npairs; ++s2) {
-#ifndef WX_NOBF
         if (s2 == a.nchunk) butterfly();
-#endif
         stage(YA, DA, 2 * s2, std::integral_constant<int, 1>());
         stage(YB, DB, 2 * s2 + 1, std::integral_constant<int, 1>());
     }
-#ifndef WX_NOBF
     if (npairs - 1 == a.nchunk) butterfly();
-#endif
     stage(YA, DA, 2 * npairs - 2, std::integral_constant<int, 1>());
     stage(YB, DB, 2 * npairs - 1, std::integral_constant<int, SKIP ? 2 : 0>());
     if (SKIP) {
@@ -543,38 +510,22 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
                 }
-#ifdef WX_NOSTORE
-                if (uok[mt] && ook[nt] && a.Dv < 0) {        // timing probe: the epilogue's arithmetic without its stores
-#else
                 if (uok[mt] && ook[nt]) {
-#endif
                     const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
                     const long ol = ob + a.out_pstride * 16;
                     half4 hi, lo;
                     split4(v, hi, lo);
-#ifdef WX_NTSTORE
-                    __builtin_nontemporal_store(hi, (half4*)((char*)a.y + ob));
-                    __builtin_nontemporal_store(lo, (half4*)((char*)a.y + ol));
-                    split4(dv, hi, lo);
-                    __builtin_nontemporal_store(hi, (half4*)((char*)a.dy + ob));
-                    __builtin_nontemporal_store(lo, (half4*)((char*)a.dy + ol));
-#else
                     *(half4*)((char*)a.y + ob) = hi;
                     *(half4*)((char*)a.y + ol) = lo;
                     split4(dv, hi, lo);
                     *(half4*)((char*)a.dy + ob) = hi;
                     *(half4*)((char*)a.dy + ol) = lo;
-#endif
                 }
             }
         }
     };
-#ifdef WX_NOEPI
-    if (a.Dv < 0) { epilogue(YA, DA, z0); epilogue(YB, DB, z0 + 1); }        // timing probe: no epilogue (results invalid)
-#else
     epilogue(YA, DA, z0);
     epilogue(YB, DB, z0 + 1);
-#endif
 }
 
 // Winograd packing of a 3x3x3 layer's weights (OIDHW float32) for conv_h3w_kernel:
@@ -651,8 +602,6 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
     static const int PA[4] = {0, 1, 2, 1}, PB[4] = {2, 2, 1, 3};
     static const float SB[4] = {-1.f, 1.f, -1.f, -1.f};
     const long plane = (long)ka.H * ka.W * 16;
-    // (walking the chunks backwards in phase 1, so that the planes phase 0 fetched last are fetched again first, was measured:
-    // +-0.1 %)
     for (int ph = 0; ph < 2; ++ph)
         for (int chunk = 0; chunk < ka.nchunk; ++chunk)
             for (int ab = 0; ab < 2; ++ab) {
