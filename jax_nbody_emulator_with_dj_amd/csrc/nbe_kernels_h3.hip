@@ -468,7 +468,11 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxl, dc[jt], 0, 0, 0);
             dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, dxh, dc[jt], 0, 0, 0);
         }
-        if (c == nchunk - 1) {                               // the parity pair (oz, oy) = pp of this half is complete
+        const bool epi = c == nchunk - 1;
+        if (epi) {                                           // the parity pair (oz, oy) = pp of this half is complete
+            // W(st + 1) has had the whole stage to land: wait for it BEFORE the stores, so that the barrier below does not
+            // have to drain them (vmcnt counts loads and stores alike; eight such drains per workgroup otherwise)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const long q = q0 + half * 128 + jq * 32 + li;
             const int z = (int)(q / HW), rem = (int)(q - (long)z * HW);
             const int yy = rem / a.W, xx = rem - yy * a.W;
@@ -478,9 +482,11 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             const bool ok[2] = {okq, okq};
             h3_store2<true, true>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
             zero_acc();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W(st + 1) has landed
+            __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W(st + 1) has landed
-        __syncthreads();
     }
 }
 
