@@ -1931,20 +1931,28 @@ static void launch_h3_v(const ConvKArgs& ka, int ct, hipStream_t s) { launch_h3_
 // On the general kernels the three input channels are a 16-channel chunk: K = 27 taps x 16 = 432 where 81 are real, and the
 // layer was bound by those MFMAs (43 % matrix-busy, 9.1 ms per launch for a layer that only has to write its output).
 // Here K = (tap, channel) = 81, padded to 96 = three k-steps of v_mfma_f32_16x16x32_f16: the workgroup keeps the weights
-// ([W hi | W lo | dW hi | dW lo] x 96 x 64 couts = 48 KB) in LDS for its whole life, stages the 6 x 34 x 3 input patch of a
-// 4 x 32 output tile as nine small f16 planes per part (part, channel, dz), and every lane GATHERS its B operand
+// ([W hi | W lo | dW hi | dW lo] x 96 x 64 couts = 48 KB) in LDS for its whole life, stages the 3 x 130 x 3 input patch of a
+// 1 x 128 output tile as nine small f16 planes per part (part, channel, dz), and every lane GATHERS its B operand
 // (8 consecutive k of one position) with 16-bit LDS reads at offsets it computed once.  18 MFMAs per 16 x 16 output tile
-// where the general kernel issued 81.  Wave w owns row w of the tile: 64 couts x 32 positions, 128 accumulator registers.
+// where the general kernel issued 81.  Wave w owns 32 columns of the tile: 64 couts x 32 positions, 128 accumulator registers.
 // Workgroups are persistent (grid = 2 per CU, tile = blockIdx.x + n gridDim.x: the tiles in flight are neighbours), patches
 // double-buffered: one barrier per tile, the next tile's 12 bytes per patch voxel are fetched under the MFMAs.
 // y = W.x + b, dy = dW.x; LeakyReLU, output gauge, hi/lo split and stores as in conv_h3g_kernel.
-constexpr int ST_ROWS = 4;
-constexpr int ST_PL = (ST_ROWS + 2) * HP_RS;                 // halves of one (part, channel, dz) patch plane: 6 x 34 = 204
-constexpr int ST_PV = 3 * ST_PL;                             // patch voxels of a tile: 612
-constexpr int ST_PATCH = 3680;                               // 2 parts x 3 channels x 3 dz planes = 3672 halves, rounded to 16 B
+// Tile shape: ST_ROWS x ST_COLS = 128 positions, four waves of 32 columns each.  The layer is bound by its stores -- 32 output
+// planes (64 couts x hi / lo x y / dy) per tile -- and a tile writes ST_COLS * 16 B contiguous bytes per row and plane: the
+// longer the runs, the faster (same-device A/B, -DNBE_STEM_ROWS=4 / 2 / 1: 26.9 / 22.9 / 20.6 ms per box, i.e. 3.0 / 3.5 /
+// 3.9 TB/s of output; profiles/r02_ab_stem_rows.txt).  One row of 128 columns: 2 KB runs.
+#ifndef NBE_STEM_ROWS
+#define NBE_STEM_ROWS 1
+#endif
+constexpr int ST_ROWS = NBE_STEM_ROWS, ST_COLS = 128 / ST_ROWS, ST_RS = ST_COLS + 2, ST_WPR = ST_COLS / 32;   // waves per row
+constexpr int ST_PL = (ST_ROWS + 2) * ST_RS;                 // halves of one (part, channel, dz) patch plane: 3 x 130 = 390
+constexpr int ST_PV = 3 * ST_PL;                             // patch voxels of a tile: 1170
+constexpr int ST_NPV = (ST_PV + 255) / 256;                  // ... per thread
+constexpr int ST_PATCH = (6 * ST_PV + 7) / 8 * 8;            // 2 parts x 3 channels x 3 dz planes (7020 halves), rounded to 16 B
 constexpr int ST_WU = 4 * 3 * 4 * 64;                        // weight units: [set 4][k-step 3][k-block 4][64 couts] x 8 halves
 constexpr int ST_VEC = ST_WU * 4 + ST_PATCH;                  // floats: after the two patch buffers, bias[64] and gout[64]
-constexpr size_t ST_LDS = (size_t)ST_WU * 16 + 2 * ST_PATCH * 2 + 2 * 64 * 4;   // 64,384 B: two workgroups per CU
+constexpr size_t ST_LDS = (size_t)ST_WU * 16 + 2 * ST_PATCH * 2 + 2 * 64 * 4;   // 77,760 B: two workgroups per CU
 
 __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
     f32x4* lds = lds_h3;
@@ -1966,25 +1974,25 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
         for (int j = 0; j < 8; ++j) {
             const int k = 32 * s + 8 * q + j;
             const int tap = k / 3, ch = k - 3 * tap, dz = tap / 9, r = tap - 9 * dz, dy = r / 3, dx = r - 3 * dy;
-            off[s][j] = k < 81 ? (ch * 3 + dz) * ST_PL + dy * HP_RS + dx : 0;     // k >= 81: zero weights, any finite value
+            off[s][j] = k < 81 ? (ch * 3 + dz) * ST_PL + dy * ST_RS + dx : 0;     // k >= 81: zero weights, any finite value
         }
 
     const int tnx = a.tnx, tny = a.tny, ntiles = a.ntiles;
     // patch voxels of this thread: pv = tid, tid + 256, tid + 512 (< 612)
-    int prow[3], pcol[3], pdz[3];
+    int prow[ST_NPV], pcol[ST_NPV], pdz[ST_NPV];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < ST_NPV; ++i) {
         const int pv = min(tid + 256 * i, ST_PV - 1);
         pdz[i] = pv / ST_PL;
         const int r = pv - pdz[i] * ST_PL;
-        prow[i] = r / HP_RS; pcol[i] = r - prow[i] * HP_RS;
+        prow[i] = r / ST_RS; pcol[i] = r - prow[i] * ST_RS;
     }
-    half4 ph[3], pl[3];
+    half4 ph[ST_NPV], pl[ST_NPV];
     auto fetch = [&](int tile) {                                 // global -> registers: 4 halves (3 channels) of hi and of lo
         const int tx = tile % tnx, t2 = tile / tnx, ty = t2 % tny, z = t2 / tny;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int yy = min(ty * ST_ROWS + prow[i], a.H - 1), xx = min(tx * HP_COLS + pcol[i], a.W - 1);
+        for (int i = 0; i < ST_NPV; ++i) {
+            const int yy = min(ty * ST_ROWS + prow[i], a.H - 1), xx = min(tx * ST_COLS + pcol[i], a.W - 1);
             const long v = ((long)(z + pdz[i]) * a.H + yy) * a.W + xx;
             ph[i] = *(const half4*)(a.x + v * 4);
             pl[i] = *(const half4*)(a.x + (a.in_pstride + v) * 4);
@@ -1993,7 +2001,7 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
     auto stage = [&](int buf) {                                  // registers -> LDS planes [part][channel][dz][row][col]
         _Float16* Pb = P + buf * ST_PATCH;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < ST_NPV; ++i) {
             const int pv = tid + 256 * i;
             if (pv < ST_PV) {
 #pragma unroll
@@ -2014,7 +2022,8 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
     if (tid < 64) Lvec[tid] = tid < 8 * a.cout_groups ? a.bias[tid] : 0.f;
     else if (tid < 128) Lvec[tid] = (gauge && tid - 64 < 8 * a.cout_groups) ? a.gout[tid - 64] : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the weights (and the first patch)
-    const int rb = wave * HP_RS + c;
+    const int wrow = wave / ST_WPR, wcol = (wave % ST_WPR) * 32;
+    const int rb = wrow * ST_RS + wcol + c;
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
         stage(buf);
@@ -2054,12 +2063,12 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 
         // epilogue: lane (c, q) holds couts 16 mt + 4 q + e of position (row wave, col 16 nt + c)
         const int tx = tile % tnx, t2 = tile / tnx, ty = t2 % tny, z = t2 / tny;
-        const int yy = ty * ST_ROWS + wave;
+        const int yy = ty * ST_ROWS + wrow;
         long o[2];
         bool ook[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int xx = tx * HP_COLS + 16 * nt + c;
+            const int xx = tx * ST_COLS + wcol + 16 * nt + c;
             ook[nt] = yy < a.Hv && xx < a.Wv;
             o[nt] = ook[nt] ? ((long)z * a.Ho + yy) * a.Wo + xx : 0;
         }
@@ -2108,11 +2117,17 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 
 static int launch_stem(ConvKArgs ka, hipStream_t s) {
     ka.tny = (ka.Hv + ST_ROWS - 1) / ST_ROWS;
-    ka.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
+    ka.tnx = (ka.Wv + ST_COLS - 1) / ST_COLS;
     const long nt = (long)ka.Dv * ka.tny * ka.tnx;
     if (nt <= 0 || nt >= (1L << 31) || ka.cout_groups > 8 || ka.nchunk != 1) return 1;
     ka.ntiles = (int)nt;
     const int grid = (int)std::min<long>(nt, 512);
+    static_assert(2 * ST_LDS <= 160 * 1024, "two workgroups per CU");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)stem_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS);
+        attr_done = true;
+    }
     hipLaunchKernelGGL(stem_h3_kernel, dim3(grid), dim3(256), ST_LDS, s, ka);
     return 0;
 }
