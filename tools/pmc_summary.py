@@ -1,11 +1,13 @@
 """Summarise a rocprofv3 --pmc ... --kernel-trace run (csv output) per kernel name prefix:
 effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time; matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES /
-(GRBM_GUI_ACTIVE / 8 * 1024 SIMDs).  Usage: python tools/pmc_summary.py <dir> [kernel-substring]"""
+(GRBM_GUI_ACTIVE / 8 * 1024 SIMDs).  Usage: python tools/pmc_summary.py <dir> [kernel-substring] [--raw]"""
 import csv, glob, os, sys
 from collections import defaultdict
 
-d = sys.argv[1]
-sub = sys.argv[2] if len(sys.argv) > 2 else "conv_h3"
+raw = "--raw" in sys.argv                      # also print every counter's total (instruction-mix passes)
+argv = [a for a in sys.argv if a != "--raw"]
+d = argv[1]
+sub = argv[2] if len(argv) > 2 else "conv_h3"
 cc = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
 kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
 dur = {}
@@ -34,3 +36,5 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1]["_ns"]):
         if c in v and v.get("SQ_WAVE_CYCLES"):
             line += "  %s %.1f %%" % (c, 100 * v[c] / v["SQ_WAVE_CYCLES"])
     print(line)
+    if raw:
+        print("    " + "  ".join("%s %.4e" % (c, x) for c, x in sorted(v.items()) if c != "_ns"))
