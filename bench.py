@@ -36,22 +36,45 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: dense f16/bf16 MFMA
 Z, OM = 0.5, 0.3
 
 
-def cpu_baseline(threads):
-    """The oracle (NumPy float32 port of the reference path) on the host cores, on a bounded sample:
-    one (1,3,128,128,128) -> 32^3 forward (BASELINE config 1, 4.3 TFLOP)."""
-    from oracle import model as M, params as P, cosmology as C
+def cpu_baseline(threads, tile_budget_s=100.0):
+    """the CPU restatement of the path (oracle/, float32, torch-CPU / oneDNN conv3d core under the oracle's
+    wiring) on the GPU box's host cores, thread count stated, on bounded samples: BASELINE config 1 -- one
+    (1,3,128,128,128) -> 32^3 forward, 4.317 TFLOP -- and, when config 1 predicts that it fits the budget, one 224^3 ->
+    128^3 sub-box (35.86 TFLOP), the unit of config 3, extrapolated x 64 to the 512^3 box.  `value` is the config-3 rate
+    (voxels of the box per second of 64 such sub-boxes); the config-1 rate is reported beside it."""
+    import torch
+    from oracle import layers as L, model as M, params as P, cosmology as C
     p = P.synthetic_params(seed=1234, mid_chan=64)
-    x = np.random.default_rng(0).standard_normal((1, 3, 128, 128, 128)).astype(np.float32)
     Dz, vf = float(C.growth_factor(Z, OM)), float(C.vel_norm(Z, OM))
+    keep = torch.get_num_threads()
+    torch.set_num_threads(threads)
+
+    def run(n):
+        x = np.random.default_rng(0).standard_normal((1, 3, n, n, n)).astype(np.float32)
+        t = time.perf_counter()
+        with L.backend('torch'):
+            d, v = M.forward(p, x, OM, Dz, vf, dtype=np.float32)
+        dt = time.perf_counter() - t
+        assert np.all(np.isfinite(d)) and np.all(np.isfinite(v))
+        return dt
+
     from threadpoolctl import threadpool_limits
     with threadpool_limits(limits=threads):
-        t = time.perf_counter()
-        d, v = M.forward(p, x, OM, Dz, vf, dtype=np.float32)
-        dt = time.perf_counter() - t
-    assert np.all(np.isfinite(d)) and np.all(np.isfinite(v))
-    return {"value": 32 ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": "one (1,3,128,128,128)->(1,3,32,32,32) StyleNBodyEmulatorVelCore forward "
-                      "(BASELINE config 1, 4.317 TFLOP), float32 NumPy oracle, %.1f s" % dt}
+        t1 = run(128)
+        predicted = t1 * 35.86 / 4.317
+        t224 = run(224) if predicted <= tile_budget_s else None
+    torch.set_num_threads(keep)
+    per_tile = t224 if t224 is not None else predicted
+    out = {"value": 512.0 ** 3 / (64 * per_tile), "unit": "voxels/s", "cores": threads, "kind": "port",
+           "sample": "float32 oracle with the torch-CPU (oneDNN) conv3d core, %d threads: config 1, one (1,3,128^3)->32^3 forward, "
+                     "%.1f s (4.317 TFLOP, %.0f voxels/s); %s; value = 512^3 / (64 x that)"
+                     % (threads, t1, 32 ** 3 / t1,
+                        "one 224^3->128^3 sub-box, %.1f s (35.86 TFLOP)" % t224 if t224 is not None else
+                        "one 224^3->128^3 sub-box NOT run (predicted %.0f s > %.0f s budget): extrapolated from config 1 by FLOPs" % (predicted, tile_budget_s)),
+           "config1": {"value": 32 ** 3 / t1, "unit": "voxels/s", "seconds": t1, "tflop": 4.317},
+           "subbox_224": {"seconds": t224, "tflop": 35.86, "measured": t224 is not None,
+                          "tflops": 35.86 / t224 if t224 else 4.317 / t1}}
+    return out
 
 
 def main():
@@ -247,12 +270,14 @@ def main():
         # two untimed calls: the first plans, allocates the workspace and pins the output arrays; a loop that rebinds
         # `res` keeps the previous pair of fields alive during the next call, so the steady state cycles through two
         # pinned pairs from the pool -- the second call pins the second pair (hipHostMalloc of 3.2 GB is not hot-path work)
-        res = emu.process_box(box, Z, OM, show_progress=False)
-        res = emu.process_box(box, Z, OM, show_progress=False)
+        # the reference's default call: process_box(input_box, z, Om) -- show_progress=True, a tqdm bar (subbox.py:139-146)
+        res = emu.process_box(box, Z, OM)
+        res = emu.process_box(box, Z, OM)
         t0 = time.perf_counter()
         for _ in range(steps):
-            res = emu.process_box(box, Z, OM, show_progress=False)
+            res = emu.process_box(box, Z, OM)
         dth = time.perf_counter() - t0
+        piped = models.get_engine(emu.model, local_rank, args.precision).query("host_pipe") == 1.0
         r0 = res[0] if vel else res
         okh = bool(np.isfinite(r0[:, ::64, ::8, ::8]).all())
         same = None
@@ -261,6 +286,7 @@ def main():
         del res
         models.release_engines()
         return {"value": float(N) ** 3 * steps / dth, "unit": "voxels/s", "ms_per_step": 1e3 * dth / steps, "steps": steps,
+                "call": "emu.process_box(box, z, Om) with default arguments (show_progress=True)", "pipelined": piped,
                 "input": "pageable NumPy float32", "output": "NumPy float32 (pinned pool)", "finite": okh,
                 "equals_resident_result": same}
 
@@ -282,7 +308,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": dtype[args.precision], "data": "synthetic",
             "config": {"workload": "process_box %d^3 ndiv=(%d,%d,%d) compute_vel=%s StyleNBodyEmulator%sCore, "
                                    "synthetic seeded weights, box resident in HBM" % (N, *ndiv, vel, "Vel" if vel else ""),
-                       "parallelism": "1 GPU" if world == 1 else "bricks %s + RCCL p2p halo exchange" % (sb.grid,),
+                       "parallelism": "1 GPU" if world == 1 else "bricks %s + %s p2p halo exchange" % (
+                           sb.grid, "RCCL (nccl backend, device to device)" if sb.backend() == "nccl" else
+                           "%s (host-staged: the one-card test rig, not a multi-GPU measurement)" % sb.backend()),
                        "internal_tiles": plan, "precision": args.precision,
                        "traffic_key": traffic_key(args.precision, plan),
                        "tiles_replayed_from_hipgraphs": main_replays},

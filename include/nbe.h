@@ -229,6 +229,27 @@ int nbe_test_modulate(nbe_ctx* ctx, const float* weight, const float* style_weig
                       int cout, int cin, int k, float s0, float s1, float eps, int first_layer,
                       float* w_n, float* dw_tot);
 
+/* Branch probe -- test instrumentation for the kink-aware parity checks (tests/kink.py).
+ * The tangent of LeakyReLUVel jumps by a factor 100 at zero (layers_vel.py:184-185), so two float evaluations of the
+ * velocity differ wherever a pre-activation is zero to within rounding.  Armed with a block of nout^3 output voxels
+ * (origin: coordinates in the output array of nbe_process_box / nbe_process_region / nbe_forward, multiples of 8; the
+ * block must lie inside one tile of the plan), the next call records, for every LeakyReLU in the block's dependency cone
+ * -- the 23 activation tensors of an (nout + 96)^3 input, core :105-195 -- which branch this library took.  The checker
+ * then evaluates the float64 oracle on that cone WITH THESE BRANCHES and requires (a) agreement with the fields at the plain
+ * tolerances on every voxel of the block and (b) that the branches differ from the oracle's own only where the oracle's
+ * pre-activation is zero to within the tolerance of that tensor.  Works with every schedule (whole tensors, z-slabs,
+ * periodic tiles, merged tiles) except brick mode.  hipGraph replay is off while a probe is armed.
+ *   nbe_probe_slots    number of activation tensors recorded (23)
+ *   nbe_probe_layout   slot i: "block/layer" of the convolution the activation follows, dims = {C, n, nw}: the bits of
+ *                      the (C, n, n, n) cone tensor as (C, n, n, nw) 32-bit words, bit b of word w = voxel x = 32 w + b;
+ *                      word_offset = its place in the buffer of nbe_probe_read
+ *   nbe_probe_read     synchronises, checks that every voxel of every cone tensor was recorded exactly once, copies out */
+int nbe_probe_begin(nbe_ctx* ctx, const int64_t origin[3], int nout);
+int nbe_probe_slots(nbe_ctx* ctx);
+int nbe_probe_layout(nbe_ctx* ctx, int slot, char* name, int name_cap, int dims[3], int64_t* word_offset);
+int nbe_probe_read(nbe_ctx* ctx, void* words, int64_t nwords);
+int nbe_probe_end(nbe_ctx* ctx);
+
 /* per-kernel HIP-event timing on the engine's stream (bench.py roofline leg) */
 int nbe_profile_enable(nbe_ctx* ctx, int on);
 int nbe_profile_reset(nbe_ctx* ctx);

@@ -81,6 +81,11 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nbe_test_modulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "nbe_probe_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "nbe_probe_slots": (C.c_int, [C.c_void_p]),
+    "nbe_probe_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "nbe_probe_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "nbe_probe_end": (C.c_int, [C.c_void_p]),
     "nbe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nbe_profile_reset": (C.c_int, [C.c_void_p]),
     "nbe_profile_count": (C.c_int, [C.c_void_p]),

@@ -15,7 +15,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -96,6 +99,45 @@ struct Layer {
 
 struct ProfEntry { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
 
+// Progress reports that do not stall the stream.  The reference's process_box shows a tqdm bar by default
+// (subbox.py:139-146, :186-193), so the default call carries a callback: the schedule records an event where a unit of work
+// ends (a decoder slab's results on their way to the host, a tile) and this thread calls the callback once the event has
+// completed -- nothing on the enqueueing side waits for the GPU.
+struct Progress {
+    struct Item { hipEvent_t ev; int done, total; };
+    nbe_progress_cb cb; void* user; int device;
+    std::thread th; std::mutex mu; std::condition_variable cv; std::deque<Item> q; bool stop = false;
+    Progress(nbe_progress_cb cb_, void* user_, int dev) : cb(cb_), user(user_), device(dev) {
+        th = std::thread([this] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                Item it;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return stop || !q.empty(); });
+                    if (q.empty()) return;
+                    it = q.front(); q.pop_front();
+                }
+                (void)hipEventSynchronize(it.ev);
+                (void)hipEventDestroy(it.ev);
+                cb(it.done, it.total, user);
+            }
+        });
+    }
+    void post(hipStream_t s, int done, int total) {              // "done of total" holds once everything enqueued on s so far has run
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+        (void)hipEventRecord(ev, s);
+        { std::lock_guard<std::mutex> lk(mu); q.push_back({ev, done, total}); }
+        cv.notify_one();
+    }
+    ~Progress() {                                               // reports what is queued, then joins
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct nbe_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -127,9 +169,11 @@ struct nbe_ctx {
         Planes skip0, td, tin; int skip0_pad = 0, tin_pad = 0;
         int D = 0, H = 0, W = 0, S = 0;
         std::vector<Arena::Blk> blks; int64_t high = 0;
+        float Dz = 0.f, vel_fac = 0.f, act_scale = 1.f; const char* ws = nullptr;   // what nbe_brick_finish must be called with
     } sst;
     // progress inside a tile (z-slab schedule): tile k of n, reported in thousandths of a tile
     nbe_progress_cb prog_cb = nullptr; void* prog_user = nullptr; int prog_k = 0, prog_n = 1;
+    Progress* prog = nullptr;                     // the reporter of the running call (process_region owns it)
     int max_tile = 512;                           // cap on the internal tile edge (output voxels); 0 = caller's grid as given
     int prec = PREC_F32;                          // arithmetic of the convolutions (nbe_set_precision)
     bool gauge = false;                           // the loaded network is wired for gauged tangents (style weights, velocity)
@@ -158,6 +202,7 @@ struct nbe_ctx {
     // comes down on a copy stream under the next slab's kernels (HostPipe, below)
     struct HostPipe {
         bool active = false, out_async = false;
+        bool tiles = false;                       // several tiles: tile k+1's planes go up and tile k-1's results come down under tile k
         const float* hbox = nullptr;              // caller's (C, S0, S1, S2) array
         bool in_pinned = false;
         int C = 0, S0 = 0, S1 = 0, S2 = 0, o0 = 0;    // o0: box plane of tile plane 0 (may be negative: periodic)
@@ -186,6 +231,18 @@ struct nbe_ctx {
     uint64_t graph_clock = 0, graph_replays = 0;
     int epoch = 0;                                // bumped whenever weights, modulation or schedule switches change
     hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
+    // Branch probe (test instrumentation, include/nbe.h): which LeakyReLU branch every activation in the dependency
+    // cone of a block of output voxels took
+    struct Probe {
+        bool on = false, tile = false;            // armed; the tile being run contains the block
+        int p[3] = {0, 0, 0}, nout = 0;           // block origin (output array coordinates) and edge
+        int o[3] = {0, 0, 0};                     // ... in the frame of the running tile's padded input (level 0)
+        struct Slot { std::string name; int C, n, nw, level; int64_t off; };
+        std::vector<Slot> slots;
+        unsigned* bits = nullptr; int64_t words = 0;
+        unsigned* count = nullptr;                // per slot: words written
+        int zr[3] = {0, 0, 0};                    // set by the schedule around a block: planes [lo, hi) of its result exist, period (0: no wrap)
+    } probe;
     // profiling
     bool prof = false;
     std::vector<ProfEntry> prof_entries;
@@ -319,7 +376,9 @@ static Planes ws_planes(nbe_ctx* c, int G, int D, int H, int W, int64_t* off_out
 }
 
 // pad > 0: the tensor carries a periodic halo of `pad` voxels in y and x around its interior (periodic-yx mode)
-struct Tensor { Planes p; int64_t off = -1; int pad = 0; };
+// org: index, in the frame of the tensor the oracle forms for this layer on the tile's padded input, of the interior
+// voxel (0, 0, 0) -- only the branch probe reads it (whole tensors of a padded tile: all zero)
+struct Tensor { Planes p; int64_t off = -1; int pad = 0; int org[3] = {0, 0, 0}; };
 static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
     Tensor t;
     t.p = ws_planes(c, planes_for(C, c->prec), D, H, W, &t.off);
@@ -360,7 +419,43 @@ static Tensor zview(const Tensor& t, int z0, int nz) {
     if (v.p.x) v.p.x += sh;
     if (v.p.dx) v.p.dx += sh;
     v.p.D = nz;
+    v.org[0] += z0;
     return v;
+}
+// frame bookkeeping of the branch probe: a tensor produced from x by `nconv` 3x3x3 layers (VALID: same origin; periodic
+// in y and x: the interior's origin moves one voxel out per layer)
+static void org_conv(const Tensor& x, int nconv, int out[3]) {
+    const int p = x.pad ? nconv : 0;
+    out[0] = x.org[0]; out[1] = x.org[1] - p; out[2] = x.org[2] - p;
+}
+static void set_org(Tensor& t, int z, int y, int x) { t.org[0] = z; t.org[1] = y; t.org[2] = x; }
+
+// Record the branch bits of the activation tensor a launch of layer L has just written: `out` points at the launch's
+// output voxel (0, 0, 0), `ext` voxels from there, whose index in the oracle's frame is `org`; periodic in y / x with the
+// extent as period when `periodic`.
+// zr = {lo, hi, period}: the layer's tensor exists for the planes [lo, hi) of a box that is periodic along z (the level-0
+// encoder of a tile that is the whole box computes N + a few planes, down_l0 exactly N / 2; what lies outside is a periodic image)
+static void probe_act(nbe_ctx* c, const Layer& L, const Planes& out, int g0, const int org[3], int ez, int ey, int ex, bool periodic,
+                      const int* zr = nullptr) {
+    auto& P = c->probe;
+    if (!P.on || !P.tile || c->dry) return;
+    const std::string name = L.block + "/" + L.layer;
+    for (size_t i = 0; i < P.slots.size(); ++i) {
+        const auto& S = P.slots[i];
+        if (S.name != name) continue;
+        ProbeLaunch a;
+        a.x = out.x; a.pstride = out.pstride; a.H = out.H; a.W = out.W; a.g0 = g0; a.prec = c->prec; a.C = S.C;
+        a.ext[0] = ez; a.ext[1] = ey; a.ext[2] = ex;
+        a.org[0] = org[0]; a.org[1] = org[1]; a.org[2] = org[2];
+        a.per[0] = 0; a.per[1] = periodic ? ey : 0; a.per[2] = periodic ? ex : 0;
+        a.zlo = zr ? zr[0] : 0; a.zhi = zr ? zr[1] : 0; a.zper = zr ? zr[2] : 0;
+        for (int d = 0; d < 3; ++d) a.o[d] = P.o[d] >> S.level;
+        a.n = S.n; a.nw = S.nw;
+        if (a.zper <= 0 && (a.o[0] + S.n <= org[0] || a.o[0] >= org[0] + ez)) return;      // this launch's planes lie outside the cone
+        a.bits = P.bits + S.off; a.count = P.count + i;
+        launch_probe_signs(a, c->stream);
+        return;
+    }
 }
 
 static int prof_entry(nbe_ctx* c, const std::string& name) {
@@ -494,19 +589,25 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
         cl.Dv = D - 4; cl.Hv = Hi - 2 * sy; cl.Wv = Wi - 2 * sy; cl.out = inner(s); cl.flags = 0;
         if (run_conv(c, *Ls, cl, has_dx)) return 1;
     }
+    int og[3];
     {
         ConvLaunch cl; cl.in = x.p; cl.Dv = D - 2; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = inner(h); cl.flags = F_ACT;
         if (run_conv(c, *L0, cl, has_dx)) return 1;
+        org_conv(x, 1, og);
+        probe_act(c, *L0, cl.out, 0, og, cl.Dv, cl.Hv, cl.Wv, pad != 0);
     }
     fill_halo(c, h);
+    org_conv(x, 2, og);
     {
         ConvLaunch cl; cl.in = h.p; cl.Dv = D - 4; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(s);
         if (fused) { cl.sk = x.p; cl.sk_off = sk_off; cl.skw = narrow_tile(L1) ? &Ls->pwn : &Ls->pw; cl.flags = (final_act ? F_ACT : 0) | (has_dx ? 0 : F_SKIP_NODX); }
         else { cl.res = inner(s); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
+        if (final_act) probe_act(c, *L1, cl.out, 0, og, cl.Dv, cl.Hv, cl.Wv, pad != 0);
     }
     fill_halo(c, s);
     tfree(c, h);
+    set_org(s, og[0], og[1], og[2]);
     *out = s;
     return 0;
 }
@@ -533,10 +634,14 @@ static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Te
         cl.Dv = ns; cl.Hv = s.p.H - 2 * pad; cl.Wv = s.p.W - 2 * pad; cl.out = inner(sv); cl.flags = 0;
         if (run_conv(c, *Ls, cl, has_dx)) return 1;
     }
+    int og[3];
     {
         ConvLaunch cl; cl.in = zview(x, jh, nh + 2).p; cl.Dv = nh; cl.Hv = H - 2; cl.Wv = W - 2; cl.out = inner(hv); cl.flags = F_ACT;
         if (x2) { cl.in2 = zview(*x2, jh, nh + 2).p; cl.csplit_ch = c->mid; }
         if (run_conv(c, *L0, cl, has_dx)) return 1;
+        org_conv(x, 1, og); og[0] += jh;                         // hidden plane j is centred on plane j + 1 of x
+        const int zh[3] = {c->probe.zr[0], c->probe.zr[1] + 2, c->probe.zr[2]};
+        probe_act(c, *L0, cl.out, 0, og, cl.Dv, cl.Hv, cl.Wv, pad != 0, zh);
     }
     fill_halo(c, hv);
     {
@@ -545,6 +650,8 @@ static int resblock_part(nbe_ctx* c, const char* name, const Tensor& x, const Te
                      if (x2) { cl.sk2 = zview(*x2, js, ns + 4).p; cl.sk_split_ch = c->mid; } }
         else { cl.res = inner(sv); cl.flags = F_RES | (final_act ? F_ACT : 0); }
         if (run_conv(c, *L1, cl, true)) return 1;
+        org_conv(x, 2, og); og[0] += js;
+        if (final_act) probe_act(c, *L1, cl.out, 0, og, cl.Dv, cl.Hv, cl.Wv, pad != 0, c->probe.zr);
     }
     fill_halo(c, sv);
     return 0;
@@ -563,6 +670,8 @@ static int downblock(nbe_ctx* c, const char* name, const Tensor& x, Tensor* out)
     if (o.off < 0) return fail("workspace exhausted in %s", name);
     ConvLaunch cl; cl.in = x.p; cl.Dv = o.p.D; cl.Hv = o.p.H; cl.Wv = o.p.W; cl.out = o.p; cl.flags = F_ACT;
     if (run_conv(c, *L, cl, true)) return 1;
+    set_org(o, x.org[0] / 2, x.org[1] / 2, x.org[2] / 2);
+    probe_act(c, *L, cl.out, 0, o.org, cl.Dv, cl.Hv, cl.Wv, false);
     *out = o;
     return 0;
 }
@@ -580,13 +689,18 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
     // f16x3 with velocity and Cin <= 64: all eight parities in one launch (up_h3_kernel: the input is read once)
     const bool up8_off = getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0;                 // A/B switch
     const bool up8 = c->prec == PREC_F16X3 && c->vel && L->pw.cin_pad <= 64 && !up8_off;
+    const int out_g0 = g0 >= 0 ? g0 : c->mid / (c->prec == PREC_F16 ? 8 : 4);
     for (int p = 0; p < (up8 ? 1 : 8); ++p) {
         ConvLaunch cl; cl.in = x.p; cl.in_off = ((int64_t)xcrop * x.p.W + xcrop);
         cl.Dv = x.p.D; cl.Hv = Hx; cl.Wv = Wx; cl.out = inner(cat);
-        cl.out_g0 = g0 >= 0 ? g0 : c->mid / (c->prec == PREC_F16 ? 8 : 4); cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
+        cl.out_g0 = out_g0; cl.osz = 2; cl.oz = (p >> 2) & 1; cl.oy = (p >> 1) & 1; cl.ox = p & 1;
         cl.flags = F_ACT; cl.set = up8 ? -1 : p;
         if (run_conv(c, *L, cl, true)) return 1;
     }
+    // output voxel 2 i + parity comes from the input voxel i of the cropped interior (the crop beyond x's own halo)
+    const int xc = xcrop - x.pad;
+    const int og[3] = {2 * x.org[0], 2 * (x.org[1] + xc), 2 * (x.org[2] + xc)};
+    probe_act(c, *L, inner(cat), out_g0, og, 2 * x.p.D, 2 * Hx, 2 * Wx, cat.pad != 0);
     return 0;
 }
 
@@ -747,7 +861,7 @@ static constexpr int PIPE_CHUNK = 32;                            // box planes p
 static int pipe_upload(nbe_ctx* c, int t0, int t1) {
     auto& P = c->pipe;
     const int64_t plane = (int64_t)P.S1 * P.S2;
-    const int D = P.S0 + 96;
+    const int D = P.S0 + 96;                                      // (a tile is at most the box + its halo deep)
     t0 = std::max(t0, 0); t1 = std::min(t1, D);
     int t = t0;
     while (t < t1) {
@@ -797,17 +911,32 @@ static int pipe_input(nbe_ctx* c, const Tensor& tin, int t0, int t1, int look, f
 
 // output planes [z, z + n) of every channel of both fields: device staging -> the caller's pinned arrays, on the
 // down stream, behind the head launch that produced them
-static int pipe_output(nbe_ctx* c, int z, int n) {
+static int pipe_output(nbe_ctx* c, int z, int n, int a1 = 0, int a2 = 0, int e1 = -1, int e2 = -1) {
     auto& P = c->pipe;
+    if (e1 < 0) e1 = P.O1;
+    if (e2 < 0) e2 = P.O2;
     HIPCHK(hipEventRecord(c->ev_down, c->stream));
     HIPCHK(hipStreamWaitEvent(c->down_stream, c->ev_down, 0));
     const int64_t plane = (int64_t)P.O1 * P.O2 * P.esz;
+    const bool whole = a1 == 0 && a2 == 0 && e1 == P.O1 && e2 == P.O2;
     for (int f = 0; f < (P.hvel ? 2 : 1); ++f) {
         char* h = f ? P.hvel : P.hdisp;
-        const char* d = f ? P.dvel : P.ddisp;
+        char* d = f ? P.dvel : P.ddisp;
         for (int ch = 0; ch < c->out_chan; ++ch) {
-            const int64_t off = ((int64_t)ch * P.O0 + z) * plane;
-            HIPCHK(hipMemcpyAsync(h + off, d + off, (size_t)n * plane, hipMemcpyDeviceToHost, c->down_stream));
+            if (whole) {
+                const int64_t off = ((int64_t)ch * P.O0 + z) * plane;
+                HIPCHK(hipMemcpyAsync(h + off, d + off, (size_t)n * plane, hipMemcpyDeviceToHost, c->down_stream));
+            } else {                                             // a tile's (n, e1, e2) block of the (C, O0, O1, O2) arrays
+                hipMemcpy3DParms mp;
+                memset(&mp, 0, sizeof mp);
+                mp.srcPtr = make_hipPitchedPtr(d, (size_t)P.O2 * P.esz, (size_t)P.O2 * P.esz, (size_t)P.O1);
+                mp.dstPtr = make_hipPitchedPtr(h, (size_t)P.O2 * P.esz, (size_t)P.O2 * P.esz, (size_t)P.O1);
+                mp.srcPos = make_hipPos((size_t)a2 * P.esz, (size_t)a1, (size_t)ch * P.O0 + z);
+                mp.dstPos = mp.srcPos;
+                mp.extent = make_hipExtent((size_t)e2 * P.esz, (size_t)e1, (size_t)n);
+                mp.kind = hipMemcpyDeviceToHost;
+                HIPCHK(hipMemcpy3DAsync(&mp, c->down_stream));
+            }
         }
     }
     return 0;
@@ -877,15 +1006,21 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
         const int n = std::min(S, zhi - z);
         const bool first = z == zlo;
         // periodic in z: the slab is exactly planes [z - 40, z - 40 + n) of the skip connection -- write it there
-        const Tensor y0 = pz ? zview(skip0, z - 40, n) : zview(y0r, 0, n);
+        Tensor y0 = pz ? zview(skip0, z - 40, n) : zview(y0r, 0, n);
         if (c->pipe.active && !c->dry && pipe_input(c, tin, z, z + n + 8, S, ho.Dz / 6.0f * c->act_scale)) return 1;
+        // frames (branch probe): plane j of the persistent slab tensors is plane z + j of the layer's whole tensor
+        { int og[3]; org_conv(zview(tin, z, n + 8), 2, og); set_org(a, og[0], og[1], og[2]);
+          org_conv(a, 2, og); set_org(y0, og[0], og[1], og[2]); }
+        // (branch probe: periodic in z, the planes [zlo, zhi + 4) of conv_l00's result and [zlo, zhi) of conv_l01's exist)
+        auto zr = [&](int extra) { c->probe.zr[0] = zlo; c->probe.zr[1] = zhi + extra; c->probe.zr[2] = pz ? D - 96 : 0; };
         if (first) {
-            if (resblock_part(c, "conv_l00", zview(tin, z, n + 8), h0, a, 0, n + 4, 0, n + 6, false, true)) return 1;
-            if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 0, n + 2, true, true)) return 1;
+            zr(4); if (resblock_part(c, "conv_l00", zview(tin, z, n + 8), h0, a, 0, n + 4, 0, n + 6, false, true)) return 1;
+            zr(0); if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 0, n + 2, true, true)) return 1;
         } else {
-            if (resblock_part(c, "conv_l00", zview(tin, z, n + 8), h0, a, 4, n, 6, n, false, true)) return 1;
-            if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 2, n, true, true)) return 1;
+            zr(4); if (resblock_part(c, "conv_l00", zview(tin, z, n + 8), h0, a, 4, n, 6, n, false, true)) return 1;
+            zr(0); if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 2, n, true, true)) return 1;
         }
+        c->probe.zr[2] = 0;
         if (z + S < zhi) {                                       // what the next slab will not recompute
             carry_planes(c, h0, n, 0, 6);
             carry_planes(c, a, n, 0, 4);
@@ -904,11 +1039,19 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
                 Tensor yv = zview(y0, d0 - z, d1 - d0);
                 ConvLaunch cl; cl.in = inner(yv); cl.Dv = tv.p.D; cl.Hv = tv.p.H; cl.Wv = tv.p.W; cl.out = tv.p; cl.flags = F_ACT;
                 if (run_conv(c, *Ld, cl, true)) return 1;
+                const int og[3] = {yv.org[0] / 2, yv.org[1] / 2, yv.org[2] / 2};
+                const int zd[3] = {22, 22 + (D - 96) / 2, pz ? (D - 96) / 2 : 0};   // periodic in z: the box's own N / 2 planes
+                probe_act(c, *Ld, cl.out, 0, og, cl.Dv, cl.Hv, cl.Wv, pad != 0, zd);     // periodic-yx: down_l0 ran on the interior only
             }
         }
     }
     tfree(c, h0); tfree(c, a); tfree(c, h1);
     if (!pz) tfree(c, y0r);
+    // frames: the skip connection is conv_l01's result cropped by 40 (its frame starts 40 voxels in; periodic-yx keeps all
+    // of y and x, whose interior sits 44 voxels into the padded frame); down_l0's output starts at plane 44 / 2 when the
+    // encoder only produced the box's own planes (pz)
+    set_org(skip0, 0, pad ? 4 : 0, pad ? 4 : 0);
+    set_org(td, pz ? 22 : 0, pad ? 22 : 0, pad ? 22 : 0);
     *skip0_out = skip0; *td_out = td;
     return 0;
 }
@@ -937,6 +1080,7 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
             launch_wrap_pad(brick_planes(c, td, c->bio.recv_lo), zview(t, 0, 22).p, 1, c->vel, c->stream, 0);
             launch_wrap_pad(brick_planes(c, td, c->bio.recv_hi), zview(t, 22 + td.p.D, 22).p, 1, c->vel, c->stream, 0);
         } else if (!c->dry) launch_wrap_pad(td.p, t.p, 1, c->vel, c->stream, pz ? 22 : 0);
+        set_org(t, pz ? td.org[0] - 22 : td.org[0], td.org[1], td.org[2]);
         tfree(c, td);
     }
 
@@ -950,14 +1094,18 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
             Planes sp = y1.p; sp.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
             launch_crop(sp, 0, cat1.p, 0, c->vel, c->stream, 16);
         }
+        set_org(cat1, y1.org[0], y1.org[1] - 16, y1.org[2] - 16);    // cropped by 16 in z only; the frame moves by 16 on every axis
         Tensor t2 = talloc(c, m, y1.p.D / 2, (y1.p.H - 2) / 2, (y1.p.W - 2) / 2);
         const Layer* Ld1 = find_layer(c, "down_l1", "conv_0");
         if (t2.off < 0 || !Ld1) return fail("workspace exhausted or missing layer (down_l1)");
         ConvLaunch cl; cl.in = inner(y1); cl.Dv = t2.p.D; cl.Hv = t2.p.H; cl.Wv = t2.p.W; cl.out = t2.p; cl.flags = F_ACT;
         if (run_conv(c, *Ld1, cl, true)) return 1;
+        set_org(t2, y1.org[0] / 2, y1.org[1] / 2, y1.org[2] / 2);
+        probe_act(c, *Ld1, cl.out, 0, t2.org, cl.Dv, cl.Hv, cl.Wv, true);   // the interior; its periodic images are copies (wrap_pad below)
         t = talloc(c, m, t2.p.D, t2.p.H + 20, t2.p.W + 20);
         if (t.off < 0) return fail("workspace exhausted (level 2 input)");
         if (!c->dry) launch_wrap_pad(t2.p, t.p, 10, c->vel, c->stream, 0);
+        set_org(t, t2.org[0], t2.org[1] - 10, t2.org[2] - 10);
         tfree(c, t2);
     } else {
         cat1 = talloc(c, 2 * m, y1.p.D - 32, y1.p.H - 32, y1.p.W - 32);
@@ -1005,6 +1153,8 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
         const int n = std::min(S, Yo - z);
         const bool first = z == 0;
         const int c0 = first ? 0 : 8, cn = first ? n + 8 : n;     // new planes of the concat tensor: [c0, c0 + cn)
+        set_org(cat, skip0.org[0] + z, skip0.org[1], skip0.org[2]);  // slab-local plane j of the concat is plane z + j of the skip connection
+        { int og[3]; org_conv(cat, 2, og); set_org(q, og[0], og[1], og[2]); }
         if (!two && !c->dry) launch_crop(zview(skip0, z + c0, cn).p, 0, zview(cat, c0, cn).p, 0, c->vel, c->stream, 0);
         if (upblock(c, "up_r0", zview(r, (z + c0) / 2, cn / 2), zview(cat, c0, cn), rcrop, two ? 0 : -1)) return 1;
         fill_halo(c, zview(cat, c0, cn));
@@ -1026,10 +1176,9 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
         }
         run_head(c, zview(y, 0, n), zview(tin, z, n + 96), ho, z);
         if (c->pipe.active && c->pipe.out_async && !c->dry && pipe_output(c, z, n)) return 1;
-        if (c->prog_cb && !c->dry && z + n < Yo) {               // the tile's last slab is reported by the sub-box loop
-            (void)hipStreamSynchronize(c->stream);
-            c->prog_cb(c->prog_k * 1000 + (int)(1000L * (z + n) / Yo), c->prog_n * 1000, c->prog_user);
-        }
+        if (c->prog && !c->dry && z + n < Yo)                    // the tile's last slab is reported by the sub-box loop
+            c->prog->post(c->pipe.active && c->pipe.out_async ? c->down_stream : c->stream,
+                          c->prog_k * 1000 + (int)(1000L * (z + n) / Yo), c->prog_n * 1000);
     }
     tfree(c, cat); tfree(c, hq); tfree(c, q); tfree(c, hy); tfree(c, y);
     tfree(c, r); tfree(c, skip0);
@@ -1091,6 +1240,7 @@ static int ensure_workspace(nbe_ctx* c, int D, int H, int W) {
     const int64_t need = workspace_need(c, D, H, W);
     if (need < 0) return 1;
     if (need > c->ws_bytes) {
+        c->sst.valid = false;
         if (c->ws) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
         HIPCHK(hipMalloc((void**)&c->ws, need));
         // padded channel planes are read (against zero weights) but never written: they must hold finite values
@@ -1110,9 +1260,11 @@ static int require_ready(nbe_ctx* c) {
 static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0, int o1, int o2,
                       int D, int H, int W, float Dz, float vel_fac, void* disp, void* velo, int out_dtype,
                       int OD, int OH, int OW, int a0, int a1, int a2) {
+    c->sst.valid = false;                                        // a tile reuses the arena: a pending brick's tensors are gone
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W), y;
     tin.pad = c->pyx ? 1 : 0;                                   // periodic-yx: (H, W) = box extent + 2, gathered from origin - 1
+    if (tin.pad) set_org(tin, 0, 48, 48);                        // its interior sits 48 voxels into the padded frame
     // core :132-134: x = x * (Dz / 6); the pipelined host path gathers slab by slab as the box arrives (pipe_input)
     if (!c->pipe.active)
         launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
@@ -1141,7 +1293,7 @@ static int run_tile(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0
                     int D, int H, int W, float Dz, float vel_fac, void* disp, void* velo, int out_dtype,
                     int OD, int OH, int OW, int a0, int a1, int a2) {
     const bool off = getenv("NBE_GRAPH") && atoi(getenv("NBE_GRAPH")) == 0;
-    if (off || c->prof || c->prog_cb || c->pipe.active || c->dry)
+    if (off || c->prof || c->prog_cb || c->pipe.active || c->dry || c->probe.on)
         return run_subbox(c, box, Db, Hb, Wb, o0, o1, o2, D, H, W, Dz, vel_fac, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2);
     nbe_ctx::GraphKey k;
     memset(&k, 0, sizeof k);
@@ -1149,7 +1301,11 @@ static int run_tile(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0
     const int geo[18] = {Db, Hb, Wb, o0, o1, o2, D, H, W, out_dtype, OD, OH, OW, a0, a1, a2, c->slab, c->prec};
     memcpy(k.geo, geo, sizeof geo);
     k.f[0] = Dz; k.f[1] = vel_fac; k.f[2] = c->act_scale;
-    k.epoch = c->epoch; k.flags = (c->pyx ? 1 : 0) | (c->pz ? 2 : 0) | (c->gauge_active ? 4 : 0) | (c->fuse ? 8 : 0);
+    // (the A/B switches that launchers read per launch are part of the key: a captured graph holds the kernels they chose)
+    auto sw = [](const char* n, int bit) { const char* e = getenv(n); return (e && atoi(e) == 0) ? (1 << bit) : 0; };
+    k.epoch = c->epoch; k.flags = (c->pyx ? 1 : 0) | (c->pz ? 2 : 0) | (c->gauge_active ? 4 : 0) | (c->fuse ? 8 : 0) |
+              sw("NBE_WINO", 4) | sw("NBE_UP8", 5) | sw("NBE_STEM", 6) | sw("NBE_H3G_TALL", 7) | sw("NBE_NARROW", 8) |
+              ((getenv("NBE_H3G_BIG") && atoi(getenv("NBE_H3G_BIG")) == 1) ? (1 << 9) : 0);
     nbe_ctx::GraphVal& g = c->graphs[k];
     g.used = ++c->graph_clock;
     if (!g.exec && g.seen++ == 0) {                              // first time: eager
@@ -1174,8 +1330,7 @@ static int run_tile(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0
             if (e == hipSuccess && !rc) e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
         }
         c->stream = user;
-        if (rc) return rc;
-        if (e != hipSuccess || !g.exec) {                        // capture is an optimisation: fall back to eager for good
+        if (rc || e != hipSuccess || !g.exec) {                  // capture is an optimisation: fall back to eager for good
             (void)hipGetLastError();
             if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
             g.exec = nullptr; g.seen = -1000000;
@@ -1417,6 +1572,7 @@ static int wire_gauge_premod(nbe_ctx* c, const nbe_layer_desc* descs, int n) {
 }
 
 static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool style) {
+    c->sst.valid = false;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     free_layers(c);
@@ -1541,6 +1697,7 @@ int nbe_destroy(nbe_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     free_layers(c);
+    (void)hipFree(c->probe.bits); (void)hipFree(c->probe.count);
     (void)hipFree(c->ws); (void)hipFree(c->box_in); (void)hipFree(c->box_out); (void)hipFree(c->gauge_flag); (void)hipFree(c->wino_flag); (void)hipFree(c->flags);
     drop_graphs(c);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
@@ -1604,6 +1761,7 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
     if (!c->have_weights) return fail("No parameters loaded. Call nbe_load_style_weights first.");
     if (!c->style) return 0;
     if (c->modulated && c->mod_Om == Om && c->mod_Dz == Dz) return 0;
+    c->sst.valid = false;                                        // a pending brick was encoded with the previous modulation
     HIPCHK(hipSetDevice(c->device));
     // s = ((Om - 0.3) * 5, Dz - 1) in float32 (core :126-128)
     const float s0 = (Om - 0.3f) * 5.0f, s1 = Dz - 1.0f;
@@ -1663,6 +1821,14 @@ int nbe_forward(nbe_ctx* c, const void* x, int D, int H, int W, float Dz, float 
         dd = c->box_out; vd = c->box_out + out_bytes;
     }
     if (prepare_range(c, xd, (int64_t)c->in_chan * D * H * W, Dz)) return 1;
+    if (c->probe.on) {
+        const int oe[3] = {OD, OH, OW};
+        c->probe.tile = true;
+        for (int d = 0; d < 3; ++d) {
+            c->probe.o[d] = c->probe.p[d];
+            if (c->probe.p[d] < 0 || c->probe.p[d] + c->probe.nout > oe[d]) return fail("branch probe: the block does not fit the output of this input");
+        }
+    }
     if (run_subbox(c, xd, D, H, W, 0, 0, 0, D, H, W, Dz, vel_fac, dd, vd, NBE_F32, OD, OH, OW, 0, 0, 0)) return 1;
     HIPCHK(hipGetLastError());
     if (!out_dev) {
@@ -1914,9 +2080,14 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     const bool pipe_off = getenv("NBE_HOST_PIPE") && atoi(getenv("NBE_HOST_PIPE")) == 0;   // read per call: A/B in one process
     auto& P = c->pipe;
     P.active = false;
-    if (!in_dev && !out_dev && !order && !pipe_off && c->slab > 0 && c->pyx && c->pz && ndiv[0] * ndiv[1] * ndiv[2] == 1 &&
-        !cb && S0 == O0 && S1 == O1 && S2 == O2 && oorigin[0] == 0 && oorigin[1] == 0 && oorigin[2] == 0) {
-        P.active = true;
+    P.tiles = false;
+    const bool whole_box = S0 == O0 && S1 == O1 && S2 == O2 && oorigin[0] == 0 && oorigin[1] == 0 && oorigin[2] == 0 &&
+                           origin[0] == 0 && origin[1] == 0 && origin[2] == 0 && region[0] == S0 && region[1] == S1 && region[2] == S2;
+    const bool one_tile = c->slab > 0 && c->pyx && c->pz && ndiv[0] * ndiv[1] * ndiv[2] == 1;
+    // several tiles that cover the box exactly (nothing left for the zeros of subbox.py:168-170): pipelined tile by tile
+    const bool many = !one_tile && (int64_t)c0 * ndiv[0] == S0 && (int64_t)c1 * ndiv[1] == S1 && (int64_t)c2 * ndiv[2] == S2;
+    if (!in_dev && !out_dev && !order && !pipe_off && whole_box && (one_tile || many)) {
+        P.active = one_tile; P.tiles = many;
         P.hbox = (const float*)box; P.in_pinned = is_pinned_host_ptr(box);
         P.C = c->in_chan; P.S0 = S0; P.S1 = S1; P.S2 = S2; P.o0 = (int)origin[0] - 48;
         P.up.assign(S0, 0); P.gz = 0; P.nstage = 0;
@@ -1939,12 +2110,13 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
             c->stage_bytes = sb;
         }
     }
-    struct PipeGuard { nbe_ctx::HostPipe& p; ~PipeGuard() { p.active = false; } } pipe_guard{P};
-    c->last_piped = P.active;
+    struct PipeGuard { nbe_ctx::HostPipe& p; ~PipeGuard() { p.active = false; p.tiles = false; } } pipe_guard{P};
+    c->last_piped = P.active || P.tiles;
+    const bool piped = P.active || P.tiles;
     if (!in_dev) {
         if (in_bytes > c->box_in_bytes) { (void)hipFree(c->box_in); c->box_in = nullptr; c->box_in_bytes = 0;
                                           HIPCHK(hipMalloc((void**)&c->box_in, in_bytes)); c->box_in_bytes = in_bytes; }
-        if (P.active) {
+        if (piped) {
             // whatever still reads the device box from the previous call must have finished before the uploads start
             HIPCHK(hipStreamSynchronize(c->stream));
         } else {
@@ -1962,15 +2134,26 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     }
     // subbox.py:168-170: outputs start as zeros (voxels beyond ndiv*crop_size stay zero); the one-tile plan of the
     // pipelined path writes every voxel
-    if ((zero_out || !out_dev) && !P.active) {
+    if ((zero_out || !out_dev) && !piped) {
         HIPCHK(hipMemsetAsync(dd, 0, out_bytes, c->stream));
         if (c->vel) HIPCHK(hipMemsetAsync(vd, 0, out_bytes, c->stream));
     }
-    const bool trace = P.active && getenv("NBE_PIPE_TRACE") && atoi(getenv("NBE_PIPE_TRACE")) != 0;
+    const bool trace = piped && getenv("NBE_PIPE_TRACE") && atoi(getenv("NBE_PIPE_TRACE")) != 0;
     const auto t_start = std::chrono::steady_clock::now();
     auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     double t_up0 = 0, t_range = 0, t_enq = 0;
-    if (P.active) {
+    std::unique_ptr<Progress> reporter;
+    if (cb) reporter.reset(new Progress(cb, user, c->device));
+    struct ProgGuard { nbe_ctx* c; ~ProgGuard() { c->prog = nullptr; c->prog_cb = nullptr; } } prog_guard{c};
+    c->prog = reporter.get();
+    if (P.tiles) {
+        // the first tile's planes, then max|x| on the host while the DMA runs
+        P.o0 = -48;
+        if (pipe_upload(c, 0, D)) return 1;
+        t_up0 = ms_since();
+        if (prepare_range(c, nullptr, (int64_t)c->in_chan * S0 * S1 * S2, Dz, (const float*)box)) return 1;
+        t_range = ms_since();
+    } else if (P.active) {
         // start the first upload, then reduce max|x| on the host while the DMA runs
         if (pipe_upload(c, 40, 40 + c->slab + 8)) return 1;
         t_up0 = ms_since();
@@ -1985,14 +2168,37 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         // subbox.py:60-66: row-major over ndiv, last axis fastest
         const int a0 = (idx / (ndiv[1] * ndiv[2])) * c0, a1 = ((idx / ndiv[2]) % ndiv[1]) * c1, a2 = (idx % ndiv[2]) * c2;
         c->prog_cb = cb; c->prog_user = user; c->prog_k = k; c->prog_n = n;
+        if (P.tiles) {                                           // this tile's planes (most were sent under the tile before)
+            P.o0 = a0 - 48;
+            if (pipe_upload(c, 0, D)) return 1;
+            HIPCHK(hipEventRecord(c->ev_up, c->up_stream));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_up, 0));
+        }
+        if (c->probe.on) {                                       // branch probe: armed for the tile that holds the block
+            auto& Pb = c->probe;
+            const int ta[3] = {(int)oorigin[0] + a0, (int)oorigin[1] + a1, (int)oorigin[2] + a2}, te[3] = {c0, c1, c2};
+            Pb.tile = true;
+            for (int d = 0; d < 3; ++d) {
+                Pb.o[d] = Pb.p[d] - ta[d];
+                if (Pb.o[d] < 0 || Pb.o[d] + Pb.nout > te[d] || Pb.o[d] % 8 != 0) Pb.tile = false;
+            }
+        }
         if (run_tile(c, bd, S0, S1, S2, (int)origin[0] + a0 - 48, (int)origin[1] + a1 - hal, (int)origin[2] + a2 - hal,
                        D, H, W, Dz, vel_fac, dd, vd, out_dtype, O0, O1, O2,
                        (int)oorigin[0] + a0, (int)oorigin[1] + a1, (int)oorigin[2] + a2)) return 1;
-        if (cb) { HIPCHK(hipStreamSynchronize(c->stream)); cb((k + 1) * 1000, n * 1000, user); }
+        if (P.tiles) {
+            if (P.out_async && pipe_output(c, a0, c0, a1, a2, c1, c2)) return 1;
+            if (k + 1 < n) {                                     // the next tile's planes go up under this tile's kernels
+                const int idn = k + 1;
+                P.o0 = (idn / (ndiv[1] * ndiv[2])) * c0 - 48;
+                if (pipe_upload(c, 0, D)) return 1;
+            }
+        }
+        if (reporter) reporter->post(piped && P.out_async ? c->down_stream : c->stream, (k + 1) * 1000, n * 1000);
     }
     c->prog_cb = nullptr;
     HIPCHK(hipGetLastError());
-    if (!out_dev && !(P.active && P.out_async)) {
+    if (!out_dev && !(piped && P.out_async)) {
         HIPCHK(hipMemcpyAsync(disp, dd, out_bytes, hipMemcpyDeviceToHost, c->stream));
         if (c->vel) HIPCHK(hipMemcpyAsync(vel, vd, out_bytes, hipMemcpyDeviceToHost, c->stream));
     }
@@ -2000,7 +2206,8 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         t_enq = ms_since();
         HIPCHK(hipStreamSynchronize(c->stream));
         const double t_comp = ms_since();
-        if (P.active) { HIPCHK(hipStreamSynchronize(c->up_stream)); HIPCHK(hipStreamSynchronize(c->down_stream)); }
+        if (piped) { HIPCHK(hipStreamSynchronize(c->up_stream)); HIPCHK(hipStreamSynchronize(c->down_stream)); }
+        reporter.reset();                                        // every report has been delivered when this returns
         if (trace)
             fprintf(stderr, "nbe pipe: first upload staged %.1f ms, max|x| on %d host threads %.1f ms, all work enqueued %.1f ms, "
                             "kernels done %.1f ms, last slab on the host %.1f ms (input %s, outputs %s)\n",
@@ -2008,6 +2215,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
                     P.out_async ? "pinned" : "pageable");
         return check_range(c);                                  // host arrays: the call is synchronous anyway
     }
+    if (reporter) { HIPCHK(hipStreamSynchronize(c->stream)); reporter.reset(); }   // a call with a progress callback is synchronous
     return 0;
 }
 
@@ -2071,6 +2279,7 @@ int nbe_host_trim(void) {
 
 // ---- brick mode: one rank's z-slab of a periodic box, level-1 context exchanged instead of recomputed ---------------
 static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* W) {
+    c->sst.valid = false;
     if (require_ready(c)) return 1;
     if (!bsize) return fail("null argument");
     const int64_t b0 = bsize[0], S1 = bsize[1], S2 = bsize[2];
@@ -2107,6 +2316,7 @@ int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float 
     launch_gather((const float*)box, c->in_chan, D, (int)bsize[1], (int)bsize[2], 0, -1, -1, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
     c->phase = 1; c->bio.send_lo = send_lo; c->bio.send_hi = send_hi;
     c->sst.D = D; c->sst.H = H; c->sst.W = W;
+    c->sst.Dz = Dz; c->sst.vel_fac = vel_fac; c->sst.act_scale = c->act_scale; c->sst.ws = c->ws;
     const HeadOut ho{nullptr, nullptr, NBE_F32, (int)bsize[0], (int)bsize[1], (int)bsize[2], 0, 0, 0, Dz, vel_fac};
     if (network_stream(c, tin, ho, c->slab)) return 1;
     HIPCHK(hipGetLastError());
@@ -2116,7 +2326,9 @@ int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float 
 int nbe_brick_finish(nbe_ctx* c, const void* recv_lo, const void* recv_hi, float Dz, float vel_fac, void* disp, void* vel, int out_dtype) {
     if (!c || !recv_lo || !recv_hi || !disp) return fail("null argument");
     if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
-    if (!c->sst.valid) return fail("nbe_brick_finish without a preceding nbe_brick_encode");
+    if (!c->sst.valid) return fail("nbe_brick_finish without a preceding nbe_brick_encode (or another call has used this context's workspace in between)");
+    if (c->sst.ws != c->ws || c->sst.Dz != Dz || c->sst.vel_fac != vel_fac || c->sst.act_scale != c->act_scale)
+        return fail("nbe_brick_finish: Dz, vel_fac and the range shift must be those of the nbe_brick_encode call it completes");
     if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
     HIPCHK(hipSetDevice(c->device));
     c->pyx = true; c->pz = false; c->zx = true; c->phase = 2;
@@ -2158,6 +2370,90 @@ int nbe_query(nbe_ctx* c, int what, double* out) {
     return 0;
 }
 
+// ---- branch probe (test instrumentation) ------------------------------------------------------------------------------
+static void probe_free(nbe_ctx* c) {
+    (void)hipFree(c->probe.bits); (void)hipFree(c->probe.count);
+    c->probe = nbe_ctx::Probe();
+}
+
+int nbe_probe_begin(nbe_ctx* c, const int64_t origin[3], int nout) {
+    if (!c || !origin) return fail("null argument");
+    if (nout < 8 || nout % 8 != 0 || nout > 128) return fail("branch probe: the block edge must be a multiple of 8 in 8..128");
+    for (int d = 0; d < 3; ++d) if (origin[d] < 0 || origin[d] % 8 != 0) return fail("branch probe: the block origin must be a non-negative multiple of 8");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    probe_free(c);
+    auto& P = c->probe;
+    P.nout = nout;
+    for (int d = 0; d < 3; ++d) P.p[d] = (int)origin[d];
+    // the activation tensors of the cone of an (nout + 96)^3 input, in execution order (core :105-195)
+    const int m = c->mid, n0 = nout + 96;
+    const int m1 = (n0 - 8) / 2, m2 = (m1 - 4) / 2, m3 = (m2 - 4) / 2, u2 = 2 * (m3 - 4), u1 = 2 * (u2 - 4), u0 = 2 * (u1 - 4);
+    struct Row { const char* name; int C, n, level; };
+    const Row rows[] = {
+        {"conv_l00/conv_0", m, n0 - 2, 0}, {"conv_l00/conv_1", m, n0 - 4, 0}, {"conv_l01/conv_0", m, n0 - 6, 0}, {"conv_l01/conv_1", m, n0 - 8, 0},
+        {"down_l0/conv_0", m, m1, 1}, {"conv_l1/conv_0", m, m1 - 2, 1}, {"conv_l1/conv_1", m, m1 - 4, 1},
+        {"down_l1/conv_0", m, m2, 2}, {"conv_l2/conv_0", m, m2 - 2, 2}, {"conv_l2/conv_1", m, m2 - 4, 2},
+        {"down_l2/conv_0", m, m3, 3}, {"conv_c/conv_0", m, m3 - 2, 3}, {"conv_c/conv_1", m, m3 - 4, 3},
+        {"up_r2/conv_0", m, u2, 2}, {"conv_r2/conv_0", 2 * m, u2 - 2, 2}, {"conv_r2/conv_1", m, u2 - 4, 2},
+        {"up_r1/conv_0", m, u1, 1}, {"conv_r1/conv_0", 2 * m, u1 - 2, 1}, {"conv_r1/conv_1", m, u1 - 4, 1},
+        {"up_r0/conv_0", m, u0, 0}, {"conv_r00/conv_0", 2 * m, u0 - 2, 0}, {"conv_r00/conv_1", m, u0 - 4, 0},
+        {"conv_r01/conv_0", m, u0 - 6, 0},
+    };
+    int64_t off = 0;
+    for (const Row& r : rows) {
+        nbe_ctx::Probe::Slot sl{r.name, r.C, r.n, (r.n + 31) / 32, r.level, off};
+        off += (int64_t)sl.C * sl.n * sl.n * sl.nw;
+        P.slots.push_back(sl);
+    }
+    P.words = off;
+    HIPCHK(hipMalloc((void**)&P.bits, off * 4));
+    HIPCHK(hipMemset(P.bits, 0, off * 4));
+    HIPCHK(hipMalloc((void**)&P.count, P.slots.size() * 4));
+    HIPCHK(hipMemset(P.count, 0, P.slots.size() * 4));
+    P.on = true; P.tile = false;
+    return 0;
+}
+
+int nbe_probe_slots(nbe_ctx* c) { return c ? (int)c->probe.slots.size() : 0; }
+
+int nbe_probe_layout(nbe_ctx* c, int slot, char* name, int cap, int dims[3], int64_t* word_offset) {
+    if (!c || slot < 0 || slot >= (int)c->probe.slots.size()) return fail("branch probe: slot out of range");
+    const auto& S = c->probe.slots[slot];
+    if (name && cap > 0) { strncpy(name, S.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (dims) { dims[0] = S.C; dims[1] = S.n; dims[2] = S.nw; }
+    if (word_offset) *word_offset = S.off;
+    return 0;
+}
+
+int nbe_probe_read(nbe_ctx* c, void* words, int64_t nwords) {
+    if (!c || !words) return fail("null argument");
+    auto& P = c->probe;
+    if (!P.on) return fail("branch probe: nbe_probe_begin has not been called");
+    if (nwords != P.words) return fail("branch probe: the buffer must hold %lld words", (long long)P.words);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<unsigned> cnt(P.slots.size());
+    HIPCHK(hipMemcpy(cnt.data(), P.count, cnt.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < P.slots.size(); ++i) {
+        const auto& S = P.slots[i];
+        const int64_t want = (int64_t)S.C * S.n * S.n * S.nw;
+        if ((int64_t)cnt[i] != want)
+            return fail("branch probe: %s was recorded %u times over %lld words (the block must lie inside one tile of the plan; "
+                        "brick mode is not probed)", S.name.c_str(), cnt[i], (long long)want);
+    }
+    HIPCHK(hipMemcpy(words, P.bits, P.words * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int nbe_probe_end(nbe_ctx* c) {
+    if (!c) return fail("null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    probe_free(c);
+    return 0;
+}
+
 // ---- test hooks -----------------------------------------------------------------------------------
 
 int nbe_test_modulate(nbe_ctx* c, const float* weight, const float* sw, const float* sb, int cout, int cin, int k,
@@ -2193,6 +2489,7 @@ static int test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x,
     const bool vel = (dw != nullptr || beta != nullptr) && dy != nullptr, has_dx = vel && dx != nullptr;
     const bool saved_vel = c->vel, saved_ga = c->gauge_active, saved_wino = c->wino_ok;
     c->vel = vel;
+    c->sst.valid = false;
     const int k = kind == 0 ? 3 : kind == 1 ? 1 : 2;
     int OD, OH, OW;
     if (kind == 0) { OD = D - 2; OH = H - 2; OW = W - 2; }

@@ -139,6 +139,19 @@ void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s, c
 void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s);
 void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s, int padz = 0);
 
+// Branch probe (test instrumentation): sign bits of one stored activation tensor over a probe region.
+// The launch's output is `ext` voxels starting at x (row pitch W, plane pitch H * W, plane stride pstride, first plane g0);
+// its voxel (0,0,0) has index `org` in the frame of the oracle's tensor for this layer, periodic in y / x with `per` where > 0.
+// The probe wants the n^3 voxels from index `o` on, all C channels, as (C, n, n, nw) 32-bit words.
+struct ProbeLaunch {
+    const float* x; int64_t pstride; int H, W, g0, prec, C;
+    int ext[3], org[3], per[3];   // per[0] is not used: z wraps through (zlo, zhi, zper)
+    int zlo, zhi, zper;           // zper > 0: the layer's tensor exists for planes [zlo, zhi) of a box periodic in z with that period
+    int o[3], n, nw;
+    unsigned* bits; unsigned* count;
+};
+void launch_probe_signs(const ProbeLaunch& a, hipStream_t s);
+
 // NBE_DBG builds: per-phase cycle totals of the f16x3 3x3x3 kernel since the last call (zeros otherwise)
 void h3q_read_stamps(double* out16, hipStream_t s);
 

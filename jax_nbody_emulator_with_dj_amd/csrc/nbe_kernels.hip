@@ -671,4 +671,53 @@ void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s, c
     if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, src2, dst, n, f);
 }
 
+// ---- branch probe (test instrumentation: include/nbe.h, "Branch probe") ---------------------------------------------
+// One thread per 32-voxel word of the probe tensor (C, n, n, nw): bit = "the LeakyReLU behind this stored activation took
+// the identity branch" = stored value > 0 (LeakyReLU keeps the sign; exactly zero is the slope branch, layers_vel.py:184-185).
+__global__ __launch_bounds__(256) void probe_signs_kernel(ProbeLaunch a) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.C * a.n * a.n * a.nw;
+    if (t >= total) return;
+    const int w = (int)(t % a.nw), jy = (int)((t / a.nw) % a.n), jz = (int)((t / ((long)a.nw * a.n)) % a.n), ch = (int)(t / ((long)a.nw * a.n * a.n));
+    // z: a tensor that exists for the planes [zlo, zhi) of a box that is periodic along z holds plane i as i, i - zper or i + zper
+    int zi = a.o[0] + jz;
+    if (a.zper > 0 && (zi < a.zlo || zi >= a.zhi)) {
+        if (zi - a.zper >= a.zlo && zi - a.zper < a.zhi) zi -= a.zper;
+        else if (zi + a.zper >= a.zlo && zi + a.zper < a.zhi) zi += a.zper;
+    }
+    int iz = zi - a.org[0], iy = a.o[1] + jy - a.org[1];
+    if (a.per[1] > 0) iy = ((iy % a.per[1]) + a.per[1]) % a.per[1];
+    if (iz < 0 || iz >= a.ext[0] || iy < 0 || iy >= a.ext[1]) return;
+    unsigned bits = 0; int covered = 0, want = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int jx = 32 * w + b;
+        if (jx >= a.n) break;
+        ++want;
+        int ix = a.o[2] + jx - a.org[2];
+        if (a.per[2] > 0) ix = ((ix % a.per[2]) + a.per[2]) % a.per[2];
+        if (ix < 0 || ix >= a.ext[2]) continue;
+        ++covered;
+        const long vox = ((long)iz * a.H + iy) * a.W + ix;
+        bool up;
+        if (a.prec == PREC_F32) {
+            up = a.x[((long)(a.g0 + ch / 4) * a.pstride + vox) * 4 + (ch & 3)] > 0.f;
+        } else {
+            const int plane = a.prec == PREC_F16X3 ? a.g0 + 2 * (ch / 8) : a.g0 + ch / 8;
+            const _Float16* hp = (const _Float16*)(a.x + ((long)plane * a.pstride + vox) * 4);
+            const float hi = (float)hp[ch & 7];
+            up = hi > 0.f;
+            if (a.prec == PREC_F16X3 && hi == 0.f) up = (float)((const _Float16*)(a.x + ((long)(plane + 1) * a.pstride + vox) * 4))[ch & 7] > 0.f;
+        }
+        bits |= (up ? 1u : 0u) << b;
+    }
+    if (covered == 0) return;
+    a.bits[t] = bits;
+    atomicAdd(a.count, covered == want ? 1u : 0x40000000u);      // a partly covered row is an error of the caller's bookkeeping
+}
+
+void launch_probe_signs(const ProbeLaunch& a, hipStream_t s) {
+    const long total = (long)a.C * a.n * a.n * a.nw;
+    if (total > 0) hipLaunchKernelGGL(probe_signs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
 }  // namespace nbe

@@ -365,6 +365,32 @@ class Engine:
         return (wn, dw) if vel else wn
 
     # ---- profiling ----------------------------------------------------------------------------
+    # ---- branch probe (test instrumentation, include/nbe.h) -----------------------------------------
+    def probe_begin(self, origin, nout=8):
+        """Arm the branch probe for the block of nout^3 output voxels at `origin` (output-array coordinates)."""
+        o = (C.c_int64 * 3)(*[int(v) for v in origin])
+        check(self._l.nbe_probe_begin(self._h, o, int(nout)))
+
+    def probe_read(self):
+        """{'block/layer': bool array (C, n, n, n)} -- True where the tangent took the identity branch."""
+        out, total, lay = {}, 0, []
+        for i in range(self._l.nbe_probe_slots(self._h)):
+            name = C.create_string_buffer(64)
+            dims, off = (C.c_int * 3)(), C.c_int64()
+            check(self._l.nbe_probe_layout(self._h, i, name, 64, dims, C.byref(off)))
+            lay.append((name.value.decode(), dims[0], dims[1], dims[2], off.value))
+            total = max(total, off.value + dims[0] * dims[1] * dims[1] * dims[2])
+        words = np.empty(total, dtype=np.uint32)
+        check(self._l.nbe_probe_read(self._h, words.ctypes.data_as(C.c_void_p), total))
+        for name, c, n, nw, off in lay:
+            w = words[off:off + c * n * n * nw].reshape(c, n, n, nw)
+            bits = np.unpackbits(w.view(np.uint8), axis=-1, bitorder='little')      # little-endian words: bit b of word w = x 32 w + b
+            out[name] = bits[..., :n].astype(bool)
+        return out
+
+    def probe_end(self):
+        check(self._l.nbe_probe_end(self._h))
+
     def profile_enable(self, on=True):
         check(self._l.nbe_profile_enable(self._h, 1 if on else 0))
 

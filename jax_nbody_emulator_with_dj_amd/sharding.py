@@ -227,6 +227,7 @@ class ShardedBox:
         self.group = group
         self.comm_stream = comm_stream
         self._halo = None                       # (send_lo, send_hi, recv_lo, recv_hi), allocated once
+        self.fallback = None                    # optional strict-float32 Engine with the same parameters (see process)
 
     def _process_zbrick(self, brick, Dz, vel_fac, disp, vel):
         """z-slab brick with ONE exchange of level-1 activations (module docstring)."""
@@ -239,9 +240,60 @@ class ShardedBox:
         exchange_z_faces(s_lo, s_hi, r_lo, r_hi, self.coords, self.grid, self.group)
         self.eng.brick_finish(r_lo, r_hi, Dz, vel_fac, disp, vel)
 
+    def backend(self):
+        """'nccl' (= RCCL, device to device over xGMI) or 'gloo' (host-staged: CPU tests and one-card rigs); None for one rank."""
+        return dist.get_backend(self.group) if self.world > 1 else None
+
     def process(self, brick, Dz, vel_fac, disp, vel, check_finite=True):
         """brick, disp, vel: CUDA tensors (C, *bshape).  Interior sub-boxes run while the halo
-        messages are in flight on the communication stream; boundary sub-boxes wait for them."""
+        messages are in flight on the communication stream; boundary sub-boxes wait for them.
+
+        Range (include/nbe.h): all ranks compute with ONE range shift (a 4-byte MAX all-reduce of max|x|), and they agree
+        on the outcome as well: when an activation leaves the f16 range on ANY rank, every rank learns it through a second
+        4-byte all-reduce and all of them either recompute the step on `fallback` (strict float32 engines, same
+        parameters; set ShardedBox.fallback) or raise NBERangeError together -- no rank walks into the next collective
+        alone.  The preset range is cleared again before this returns, whatever happens."""
+        from .engine import NBERangeError
+        try:
+            self._process(self.eng, brick, Dz, vel_fac, disp, vel)
+            bad, msg = 0, ""
+            if check_finite:
+                try:
+                    self.eng.check_finite()
+                except NBERangeError as e:
+                    bad, msg = 1, str(e)
+        finally:
+            self.eng.set_input_range(None)
+        if not check_finite:
+            return disp, vel
+        if self.world > 1:
+            flag = torch.tensor([bad], dtype=torch.int32, device="cpu" if dist.get_backend(self.group) == "gloo" else brick.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            anybad = int(flag.item())
+        else:
+            anybad = bad
+        if anybad:
+            if self.fallback is None:
+                raise NBERangeError(msg or "non-finite values on another rank of the sharded box: an activation left the range "
+                                           "of the f16-based arithmetic; rerun the step with strict float32 engines")
+            import warnings
+            warnings.warn("%s -- recomputing this box with the strict float32 engines on all ranks"
+                          % (msg or "an activation left the f16 range on another rank"), RuntimeWarning)
+            try:
+                self._process(self.fallback, brick, Dz, vel_fac, disp, vel)
+                self.fallback.check_finite()
+            finally:
+                self.fallback.set_input_range(None)
+        return disp, vel
+
+    def _process(self, eng, brick, Dz, vel_fac, disp, vel):
+        self.eng, keep = eng, self.eng
+        try:
+            return self._process_on(brick, Dz, vel_fac, disp, vel)
+        finally:
+            self.eng = keep
+
+    def _process_on(self, brick, Dz, vel_fac, disp, vel):
         cur = torch.cuda.current_stream(brick.device)
         # one range shift for the whole box (include/nbe.h, "Range"): max |x| over all bricks, a 4-byte all-reduce --
         # every rank then computes its brick with the arithmetic a single-GPU run of the box would use
@@ -253,8 +305,6 @@ class ShardedBox:
         self.eng.set_input_range(float(amax.item()))
         if self.zbricks:
             self._process_zbrick(brick, Dz, vel_fac, disp, vel)
-            if check_finite:
-                self.eng.check_finite()
             return disp, vel
         # the engine merges sub-boxes into larger tiles when that is exact (nbe_plan_tiles); split on that grid
         nd = self.eng.plan_tiles(self.bshape, self.nd_local, periodic_box=False)
@@ -275,6 +325,4 @@ class ShardedBox:
         # haloed only along the split axes: along the others the region is the periodic box itself
         origin = tuple(PAD if g > 1 else 0 for g in self.grid)
         self.eng.process_region(H, origin, self.bshape, nd, Dz, vel_fac, disp, vel, order=sorted(boundary))
-        if check_finite:
-            self.eng.check_finite()              # synchronises; raises NBERangeError instead of returning inf / NaN
         return disp, vel

@@ -14,12 +14,36 @@ Follows the reference layer files:
 All functions work on UNBATCHED arrays (C, D, H, W) in a caller-chosen dtype
 (float64 = truth, float32 = envelope).  Convolutions are evaluated tap by tap
 as (voxels x Cin) @ (Cin x Cout) matrix products.
+
+Two interchangeable evaluators of the stride-1 VALID cross-correlation:
+  'numpy'  (default) the tap-wise GEMM below -- the definition every small test uses;
+  'torch'  torch.nn.functional.conv3d on the CPU, in z-chunks that bound its im2col buffer -- an independent
+           implementation of the same sum (pinned against the NumPy one in tests/test_oracle_pins.py), 6x faster
+           in float64: used for the production-width fixtures (224^3 sub-boxes), the kink-aware parity checks that
+           run the oracle at test time, and bench.py's cpu_baseline ("torch-CPU/oneDNN conv core").
+Select with `with layers.backend('torch'): ...`.
 """
+
+import contextlib
 
 import numpy as np
 from numpy.lib.stride_tricks import as_strided
 
 NEG_SLOPE = 0.01
+
+_BACKEND = ['numpy']
+
+
+@contextlib.contextmanager
+def backend(name):
+    """Evaluate the stride-1 convolutions with 'numpy' (tap-wise GEMM) or 'torch' (CPU conv3d) inside the block."""
+    if name not in ('numpy', 'torch'):
+        raise ValueError("backend must be 'numpy' or 'torch'")
+    _BACKEND.append(name)
+    try:
+        yield
+    finally:
+        _BACKEND.pop()
 
 
 # --------------------------------------------------------------------------
@@ -90,9 +114,42 @@ def _conv_valid_s1(x, w, zblock=8):
     return np.ascontiguousarray(np.moveaxis(out, -1, 0))
 
 
+def _conv_valid_s1_torch(x, w, im2col_bytes=1.5e9):
+    """The same sum through torch.nn.functional.conv3d (CPU).  float64 goes in z-chunks: torch's float64 path builds an
+    im2col buffer of k^3 * Cin values per output voxel; float32 (oneDNN) takes the tensor whole."""
+    import torch
+    Cin, D, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[2]
+    Do, Ho, Wo = D - k + 1, H - k + 1, W - k + 1
+    xt = torch.from_numpy(np.ascontiguousarray(x))[None]
+    wt = torch.from_numpy(np.ascontiguousarray(w))
+    with torch.no_grad():
+        if x.dtype == np.float32:
+            return torch.nn.functional.conv3d(xt, wt)[0].numpy()
+        out = np.empty((Cout, Do, Ho, Wo), dtype=x.dtype)
+        ot = torch.from_numpy(out)
+        nz = max(1, int(im2col_bytes / (k ** 3 * Cin * Ho * Wo * x.dtype.itemsize)))
+        for z0 in range(0, Do, nz):
+            z1 = min(Do, z0 + nz)
+            ot[:, z0:z1] = torch.nn.functional.conv3d(xt[:, :, z0:z1 + k - 1], wt)[0]
+    return out
+
+
+def _iadd(a, b):
+    """a += b (multi-threaded through torch when that backend is selected: the production-width tensors are GBs)."""
+    if _BACKEND[-1] == 'torch':
+        import torch
+        torch.from_numpy(a).add_(torch.from_numpy(np.ascontiguousarray(b)) if b.shape == a.shape else torch.from_numpy(np.ascontiguousarray(b)).expand(a.shape))
+    else:
+        a += b
+    return a
+
+
 def _conv_valid(x, w, stride=1, zblock=16):
     """VALID cross-correlation, x (Cin,D,H,W), w (Cout,Cin,k,k,k) -> (Cout,Do,Ho,Wo)."""
     if stride == 1:
+        if _BACKEND[-1] == 'torch' and w.shape[2] > 1:
+            return _conv_valid_s1_torch(x, w)
         return _conv_valid_s1(x, w)
     Cin, D, H, W = x.shape
     Cout, Cin2, k = w.shape[0], w.shape[1], w.shape[2]
@@ -121,6 +178,14 @@ def conv3(x, w):
 
 
 def conv1(x, w):
+    if _BACKEND[-1] == 'torch':
+        # 1x1x1: one (Cout x Cin) @ (Cin x voxels) product in the tensor's own channels-first layout
+        import torch
+        xt = torch.from_numpy(x) if x.flags.writeable else torch.from_numpy(np.array(x))
+        Cin = x.shape[0]
+        with torch.no_grad():
+            y = torch.from_numpy(np.ascontiguousarray(w[:, :, 0, 0, 0])) @ xt.reshape(Cin, -1)
+        return y.numpy().reshape((w.shape[0],) + x.shape[1:])
     return _conv_valid(x, w, 1)
 
 
@@ -157,17 +222,25 @@ _CONV = {'conv3': conv3, 'skip': conv1, 'down': down2, 'up': up2}
 
 def conv_layer(kind, x, w, b):
     """Displacement-only layer: y = conv(x, w) + b   (style_layers.py:86-99)."""
-    return _CONV[kind](x, w) + b[:, None, None, None]
+    y = _CONV[kind](x, w)
+    return _iadd(y, b[:, None, None, None])
 
 
 def conv_layer_vel(kind, x, dx, w, dw, b):
     """y = conv(x,w)+b ; dy = conv(x,dw) [+ conv(dx,w)]  (style_layers_vel.py:129-141).
-    The bias enters y only."""
+    The bias enters y only.  (Sums are formed in place: the production-width fixtures hold 5 GB tensors.)"""
     f = _CONV[kind]
-    y = f(x, w) + b[:, None, None, None]
-    dy = f(x, dw)
+    if kind == 'conv3' and _BACKEND[-1] == 'torch':
+        # conv(x, w) and conv(x, dw) as one convolution with 2 Cout outputs: x is unfolded once
+        co = w.shape[0]
+        ydy = f(x, np.concatenate([w, dw], axis=0))
+        y, dy = ydy[:co], ydy[co:]
+    else:
+        y = f(x, w)
+        dy = f(x, dw)
+    _iadd(y, b[:, None, None, None])
     if dx is not None:
-        dy = dy + f(dx, w)
+        _iadd(dy, f(dx, w))
     return y, dy
 
 
@@ -180,7 +253,33 @@ def leaky_relu(x, slope=NEG_SLOPE):
     return np.where(x >= 0, x, x.dtype.type(slope) * x)
 
 
-def leaky_relu_vel(x, dx, slope=NEG_SLOPE):
-    """layers_vel.py:182-186: the tangent takes the slope branch at x == 0."""
+def leaky_relu_vel(x, dx, slope=NEG_SLOPE, branch=None):
+    """layers_vel.py:182-186: the tangent takes the slope branch at x == 0.
+
+    branch: optional boolean array, True where the TANGENT is to take the identity branch instead of the
+    reference's `x > 0` -- the kink-aware parity checks (tests/kink.py) evaluate the oracle with the branch
+    decisions another evaluation took; the primal always follows the reference."""
     sl = x.dtype.type(slope)
-    return np.where(x >= 0, x, sl * x), np.where(x > 0, dx, sl * dx)
+    up = (x > 0) if branch is None else branch
+    return np.where(x >= 0, x, sl * x), np.where(up, dx, sl * dx)
+
+
+def leaky_relu_vel_(x, dx, slope=NEG_SLOPE, branch=None):
+    """leaky_relu_vel written into its arguments (x and dx must be arrays nobody else reads)."""
+    sl = x.dtype.type(slope)
+    if _BACKEND[-1] == 'torch' and x.flags.c_contiguous and dx.flags.c_contiguous:
+        import torch
+        xt, dxt = torch.from_numpy(x), torch.from_numpy(dx)
+        up = (xt > 0) if branch is None else torch.from_numpy(np.ascontiguousarray(branch))
+        torch.where(up, dxt, dxt * float(sl), out=dxt)
+        torch.where(xt >= 0, xt, xt * float(sl), out=xt)
+        return x, dx
+    up = (x > 0) if branch is None else branch
+    np.multiply(dx, sl, out=dx, where=~up)
+    np.multiply(x, sl, out=x, where=x < 0)
+    return x, dx
+
+
+def leaky_relu_(x, slope=NEG_SLOPE):
+    np.multiply(x, x.dtype.type(slope), out=x, where=x < 0)
+    return x

@@ -72,38 +72,40 @@ def _layer(W, vel, block, layer, kind, x, dx):
     return L.conv_layer(kind, x, w, b), None
 
 
-def _act(vel, x, dx):
+def _act(W, vel, x, dx, name):
+    """LeakyReLU[Vel] on freshly computed arrays, in place.  `name` is 'block/layer' of the convolution whose output
+    is activated; W.branch_hook(name, x), when set, supplies the branch the tangent takes (layers.leaky_relu_vel)."""
     if vel:
-        return L.leaky_relu_vel(x, dx)
-    return L.leaky_relu(x), None
+        hook = getattr(W, 'branch_hook', None)
+        return L.leaky_relu_vel_(x, dx, branch=None if hook is None else hook(name, x))
+    return L.leaky_relu_(x), None
 
 
 def resnet_block(W, vel, name, x, dx):
-    """style_blocks_vel.py:96-166."""
+    """style_blocks_vel.py:96-166.  The reference evaluates the 1x1x1 skip on the whole input and crops it by the
+    number of convolutions; a 1x1x1 layer commutes with cropping, so the skip is evaluated on the cropped input here
+    (same values), after the main branch, and added in place -- at production width a level-0 tensor pair is 11 GB."""
     seq = BLOCK_SEQ[name]
     last_act = seq[-1] == 'A'
     main = seq[:-1] if last_act else seq
-    y, dy = _layer(W, vel, name, 'skip', 'skip', x, dx)
     ncv = main.count('C')
-    if ncv > 0:
-        c = ncv
-        y = y[:, c:-c, c:-c, c:-c]
-        if vel:
-            dy = dy[:, c:-c, c:-c, c:-c]
+    x_in, dx_in = x, dx
     ci = 0
     for ch in main:
         if ch == 'C':
             x, dx = _layer(W, vel, name, 'conv_%d' % ci, 'conv3', x, dx)
             ci += 1
         elif ch == 'A':
-            x, dx = _act(vel, x, dx)
+            x, dx = _act(W, vel, x, dx, '%s/conv_%d' % (name, ci - 1))
         else:
             raise ValueError('Layer type "%s" not supported. Use C (conv) or A (activation).' % ch)
-    x = x + y
+    c = ncv
+    y, dy = _layer(W, vel, name, 'skip', 'skip', _crop(x_in, c) if c else x_in, _crop(dx_in, c) if c else dx_in)
+    L._iadd(x, y)
     if vel:
-        dx = dx + dy
+        L._iadd(dx, dy)
     if last_act:
-        x, dx = _act(vel, x, dx)
+        x, dx = _act(W, vel, x, dx, '%s/conv_%d' % (name, ci - 1))
     return x, dx
 
 
@@ -118,7 +120,7 @@ def resample_block(W, vel, name, x, dx):
             x, dx = _layer(W, vel, name, 'conv_%d' % ci, 'down', x, dx)
             ci += 1
         elif ch == 'A':
-            x, dx = _act(vel, x, dx)
+            x, dx = _act(W, vel, x, dx, '%s/conv_%d' % (name, ci - 1))
         else:
             raise ValueError('Layer type "%s" not supported.' % ch)
     return x, dx
@@ -128,35 +130,46 @@ def _crop(a, c):
     return None if a is None else a[:, c:-c, c:-c, c:-c]
 
 
+def _crop_copy(a, c):
+    """A skip connection's centre crop as an array of its own, so that the uncropped tensor can be released."""
+    return None if a is None else np.ascontiguousarray(a[:, c:-c, c:-c, c:-c])
+
+
 def _cat(a, b):
     return None if a is None else np.concatenate([a, b], axis=0)
 
 
 def forward_single(params, x, Om, Dz, vel_fac, premodulated, compute_vel,
-                   dtype=np.float64, eps=1e-8):
-    """One batch element.  x (C, D, H, W).  Returns disp or (disp, vel)."""
+                   dtype=np.float64, eps=1e-8, branch_hook=None):
+    """One batch element.  x (C, D, H, W).  Returns disp or (disp, vel).
+
+    branch_hook(name, pre_activation) -> boolean array or None: called at every LeakyReLUVel with the 'block/layer'
+    name of the convolution it follows; a returned array replaces `pre_activation > 0` as the branch of the TANGENT
+    (tests/kink.py: the oracle evaluated with the branch decisions of the evaluation under test)."""
     dt = np.dtype(dtype)
     vel = compute_vel
     Dz = dt.type(Dz)
     s = None if premodulated else L.style_vector(Om, Dz, dt)
     W = _Weights(params, premodulated, compute_vel, s, dt, eps)
+    W.branch_hook = branch_hook
 
     x = np.asarray(x, dtype=dt) * (Dz / dt.type(6.0))          # core :132-134
     dx = None
     x0 = x[:, 48:-48, 48:-48, 48:-48]                          # core :139
 
+    x0 = np.ascontiguousarray(x0)
     x, dx = resnet_block(W, vel, 'conv_l00', x, dx)
     y0, dy0 = resnet_block(W, vel, 'conv_l01', x, dx)
     x, dx = resample_block(W, vel, 'down_l0', y0, dy0)
-    y0, dy0 = _crop(y0, 40), _crop(dy0, 40)
+    y0, dy0 = _crop_copy(y0, 40), _crop_copy(dy0, 40)
 
     y1, dy1 = resnet_block(W, vel, 'conv_l1', x, dx)
     x, dx = resample_block(W, vel, 'down_l1', y1, dy1)
-    y1, dy1 = _crop(y1, 16), _crop(dy1, 16)
+    y1, dy1 = _crop_copy(y1, 16), _crop_copy(dy1, 16)
 
     y2, dy2 = resnet_block(W, vel, 'conv_l2', x, dx)
     x, dx = resample_block(W, vel, 'down_l2', y2, dy2)
-    y2, dy2 = _crop(y2, 4), _crop(dy2, 4)
+    y2, dy2 = _crop_copy(y2, 4), _crop_copy(dy2, 4)
 
     x, dx = resnet_block(W, vel, 'conv_c', x, dx)
 
@@ -182,7 +195,7 @@ def forward_single(params, x, Om, Dz, vel_fac, premodulated, compute_vel,
 
 
 def forward(params, x, Om=None, Dz=None, vel_fac=None, premodulated=False, compute_vel=True,
-            dtype=np.float64, eps=1e-8):
+            dtype=np.float64, eps=1e-8, branch_hook=None):
     """Batched front end: x (B, C, D, H, W); Om, Dz, vel_fac scalars or (B,)."""
     x = np.asarray(x)
     B = x.shape[0]
@@ -191,7 +204,7 @@ def forward(params, x, Om=None, Dz=None, vel_fac=None, premodulated=False, compu
     outs = [forward_single(params, x[i],
                            None if Om_ is None else Om_[i], Dz_[i],
                            None if vf_ is None else vf_[i],
-                           premodulated, compute_vel, dtype, eps) for i in range(B)]
+                           premodulated, compute_vel, dtype, eps, branch_hook) for i in range(B)]
     if compute_vel:
         return np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs])
     return np.stack(outs)

@@ -225,8 +225,8 @@ def test_winograd_schedules_agree_to_rounding(monkeypatch):
     how a launch pairs its planes -- hence on the schedule.  Against the direct-kernel field (NBE_WINO=0, what the
     schedule-equivalence tests compare bit for bit) the default must agree to float32 rounding, on the merged tile and on
     the caller's grid: displacement everywhere; velocity in the median and in relative L2 over the voxels that no LeakyReLU
-    kink separates (tests/test_gpu_range.py::_kink_robust_vel has the reasoning; a kink flips where a pre-activation is zero
-    to within rounding and moves that voxel's tangent by up to a factor 100)."""
+    kink separates (a kink flips where a pre-activation is zero to within rounding and moves that voxel's tangent by up to a
+    factor 100; tests/test_gpu_kink.py walks the same schedules causally, branch probe + float64 oracle)."""
     from jax_nbody_emulator_with_dj_amd.models import get_engine
     m = J.StyleNBodyEmulatorVelCore(mid_chan=8)
     p = _synthetic(13, 8)
@@ -372,10 +372,10 @@ def test_host_array_pipeline_equals_resident(prec, monkeypatch):
         _lib.check(eng._l.nbe_process_box(eng._h, ptr(box), (C.c_int64 * 3)(*size), (C.c_int * 3)(*ndiv), (C.c_int * 6)(*([48] * 6)),
                                          Dz, vf, ptr(d2), ptr(v2), 0, C.cast(None, _lib.PROGRESS_CB), None))
         assert np.array_equal(d2, d) and np.array_equal(v2, v)
-        # the caller's grid run exactly (no merging into one periodic tile) takes the plain path
+        # the caller's grid run exactly (no merging into one periodic tile): pipelined tile by tile
         eng.set_max_tile(0)
         d3, v3 = eng.process_box(box, size, ndiv, pad, Dz, vf)
-        assert eng.query("host_pipe") == 0.0
+        assert eng.query("host_pipe") == 1.0
         d3t, v3t = eng.process_box(torch.from_numpy(box).cuda(), size, ndiv, pad, Dz, vf)
         eng.set_max_tile(512)
         assert np.array_equal(d3, d3t.cpu().numpy()) and np.array_equal(v3, v3t.cpu().numpy())
@@ -389,6 +389,52 @@ def test_host_array_pipeline_equals_resident(prec, monkeypatch):
     finally:
         eng.set_slab(-1)
         eng.set_max_tile(512)
+
+
+def test_default_call_keeps_the_pipeline_and_reports_progress(monkeypatch):
+    """The reference's default call is process_box(input_box, z, Om) with show_progress=True (subbox.py:139-146, tqdm
+    :186-193).  The progress callback is fired from a host thread behind recorded events, so the default call stays on
+    the pipelined host path (no stream synchronisation per slab or tile): same fields as show_progress=False, reports
+    monotone and complete, one-tile and tile-by-tile plans."""
+    from jax_nbody_emulator_with_dj_amd.models import get_engine
+    p = _synthetic(23, 8)
+    size, ndiv = (160, 64, 64), (2, 2, 2)
+    box = np.random.default_rng(9).standard_normal((3,) + size).astype(np.float32)
+    emu = J.create_emulator(load_params=False, processor_config=J.SubboxConfig(size=size, ndiv=ndiv), mid_chan=8)
+    emu.params = p
+    emu.processor.params = p
+    eng = get_engine(emu.model, None)
+    pad = ((48, 48),) * 3
+    Dz, vf = float(np.float32(J.growth_factor(Z, OM))), float(np.float32(J.vel_norm(Z, OM)))
+    try:
+        for max_tile, slab in ((512, 32), (512, -1), (0, -1), (80, -1)):
+            eng.set_max_tile(max_tile); eng.set_slab(slab)
+            d0, v0 = emu.process_box(box, Z, OM, show_progress=False)
+            assert eng.query("host_pipe") == 1.0, (max_tile, slab)
+            d1, v1 = emu.process_box(box, Z, OM)                          # the reference's default call
+            assert eng.query("host_pipe") == 1.0, (max_tile, slab)
+            assert np.array_equal(d0, d1) and np.array_equal(v0, v1)
+            seen = []
+            eng.ensure_params(p, False); eng.set_cosmology(np.float32(OM), np.float32(Dz))
+            d2, v2 = eng.process_box(box, size, ndiv, pad, Dz, vf, progress=lambda done, total, user: seen.append((done, total)))
+            assert np.array_equal(d2, d0) and np.array_equal(v2, v0)
+            assert seen and seen[-1][0] == seen[-1][1] and all(a[0] <= b[0] for a, b in zip(seen, seen[1:])), seen
+            ntiles = int(np.prod(eng.plan_tiles(size, ndiv)))
+            assert len(seen) >= ntiles and all(t == ntiles * 1000 for _, t in seen), (seen, ntiles)
+            # resident tensors with a callback: synchronous, same reports
+            import torch
+            seen_t = []
+            dt, vt = eng.process_box(torch.from_numpy(box).cuda(), size, ndiv, pad, Dz, vf,
+                                     progress=lambda done, total, user: seen_t.append(done))
+            assert seen_t == [a for a, _ in seen] and np.array_equal(dt.cpu().numpy(), d0)
+        # a box that the sub-boxes do not cover (size % ndiv != 0: trailing voxels stay zero) takes the plain path
+        size2 = (168, 64, 64)
+        box2 = np.random.default_rng(10).standard_normal((3,) + size2).astype(np.float32)
+        eng.set_max_tile(0)
+        d, v = eng.process_box(box2, size2, (5, 1, 1), pad, Dz, vf)
+        assert eng.query("host_pipe") == 0.0 and np.all(d[:, 165:] == 0) and np.any(d[:, :165] != 0)
+    finally:
+        eng.set_max_tile(512); eng.set_slab(-1)
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "f32", "f16"])
