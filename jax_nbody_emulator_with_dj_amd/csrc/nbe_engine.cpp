@@ -855,6 +855,7 @@ static int check_range(nbe_ctx* c) {
 // Pipelined host path (HostPipe).  The tile is the whole periodic box; tile plane t is box plane (o0 + t) mod S0.
 // ------------------------------------------------------------------------------------------------
 static constexpr int PIPE_CHUNK = 32;                            // box planes per staged upload
+static constexpr int PIPE_EDGE = 32;                             // planes of the first encoder slab and of the last decoder slab
 
 // box planes behind tile planes [t0, t1) -> device box (enqueued on up_stream; pageable sources go through the pinned
 // staging ring, filled by host threads)
@@ -1002,12 +1003,16 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
     Tensor h1 = alloc_hidden(c, m, S + 2, a, block_fused(c, L01, true));
     Tensor y0r = pz ? Tensor() : tallocp(c, m, S, Hi - 4 * sy, Wi - 4 * sy, pad);
     if (h0.off < 0 || a.off < 0 || h1.off < 0 || (!pz && y0r.off < 0)) return fail("workspace exhausted (level-0 encoder slabs)");
-    for (int z = zlo; z < zhi; z += S) {
-        const int n = std::min(S, zhi - z);
+    // Pipelined host path: the first slab is short (PIPE_EDGE planes), so that the kernels start as soon as a small first
+    // upload has landed; the decoder's last slab is short for the same reason at the other end (its copy to the host is
+    // the only one nothing hides).  Slabs start on even planes either way, so the fields do not change.
+    for (int z = zlo, n = 0; z < zhi; z += n) {
+        n = std::min((c->pipe.active && z == zlo) ? std::min(S, PIPE_EDGE) : S, zhi - z);
+        const int n_next = std::min(S, zhi - (z + n));
         const bool first = z == zlo;
         // periodic in z: the slab is exactly planes [z - 40, z - 40 + n) of the skip connection -- write it there
         Tensor y0 = pz ? zview(skip0, z - 40, n) : zview(y0r, 0, n);
-        if (c->pipe.active && !c->dry && pipe_input(c, tin, z, z + n + 8, S, ho.Dz / 6.0f * c->act_scale)) return 1;
+        if (c->pipe.active && !c->dry && pipe_input(c, tin, z, z + n + 8, n_next, ho.Dz / 6.0f * c->act_scale)) return 1;
         // frames (branch probe): plane j of the persistent slab tensors is plane z + j of the layer's whole tensor
         { int og[3]; org_conv(zview(tin, z, n + 8), 2, og); set_org(a, og[0], og[1], og[2]);
           org_conv(a, 2, og); set_org(y0, og[0], og[1], og[2]); }
@@ -1021,7 +1026,7 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
             zr(0); if (resblock_part(c, "conv_l01", a, h1, y0, 0, n, 2, n, true, true)) return 1;
         }
         c->probe.zr[2] = 0;
-        if (z + S < zhi) {                                       // what the next slab will not recompute
+        if (z + n < zhi) {                                       // what the next slab will not recompute
             carry_planes(c, h0, n, 0, 6);
             carry_planes(c, a, n, 0, 4);
             carry_planes(c, h1, n, 0, 2);
@@ -1149,8 +1154,10 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
     Tensor q = tallocp(c, m, S + 4, Hs - 2 * sy, Ws - 2 * sy, pad), hy = alloc_hidden(c, m, S + 2, q, block_fused(c, Lr01, true));
     Tensor y = tallocp(c, c->out_chan, S, Hs - 4 * sy, Ws - 4 * sy, pad);
     if (cat.off < 0 || hq.off < 0 || q.off < 0 || hy.off < 0 || y.off < 0) return fail("workspace exhausted (level-0 decoder slabs)");
-    for (int z = 0; z < Yo; z += S) {
-        const int n = std::min(S, Yo - z);
+    for (int z = 0, n = 0; z < Yo; z += n) {
+        n = std::min(S, Yo - z);
+        if (c->pipe.active && c->pipe.out_async && Yo - z > PIPE_EDGE && Yo - z - n < PIPE_EDGE)
+            n = Yo - z - PIPE_EDGE;                              // leave a short last slab (pipelined host path, see stream_encode)
         const bool first = z == 0;
         const int c0 = first ? 0 : 8, cn = first ? n + 8 : n;     // new planes of the concat tensor: [c0, c0 + cn)
         set_org(cat, skip0.org[0] + z, skip0.org[1], skip0.org[2]);  // slab-local plane j of the concat is plane z + j of the skip connection
@@ -1168,7 +1175,7 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
             if (resblock_part(c, "conv_r00", sk, hq, q, 4, n, 6, n, true, true, up2)) return 1;
             if (resblock_part(c, "conv_r01", q, hy, y, 0, n, 2, n, true, false)) return 1;
         }
-        if (z + S < Yo) {
+        if (z + n < Yo) {
             carry_planes(c, cat, n, 0, 8);
             carry_planes(c, hq, n, 0, 6);
             carry_planes(c, q, n, 0, 4);
@@ -2155,7 +2162,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         t_range = ms_since();
     } else if (P.active) {
         // start the first upload, then reduce max|x| on the host while the DMA runs
-        if (pipe_upload(c, 40, 40 + c->slab + 8)) return 1;
+        if (pipe_upload(c, 40, 40 + std::min(c->slab, PIPE_EDGE) + 8)) return 1;
         t_up0 = ms_since();
         if (prepare_range(c, nullptr, (int64_t)c->in_chan * S0 * S1 * S2, Dz, (const float*)box)) return 1;
         t_range = ms_since();
