@@ -164,22 +164,35 @@ int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3],
                        float Dz, float vel_fac, void* disp, void* vel, int out_dtype,
                        const int64_t out_size[3], const int64_t out_origin[3]);
 
-/* Brick mode of a sharded box (no reference counterpart: the reference is single-device).  The ranks of a node cut the
- * periodic box into slabs along z; every rank holds its brick haloed by 48 planes of the raw input on either side
- * ((C, b0 + 96, S1, S2), device memory) and is periodic in y and x by itself.  The network's z context below the
- * full-resolution level -- 22 planes of the down_l0 output on either side, which padded bricks would recompute from 44
- * more planes of level-0 work each -- is EXCHANGED between neighbours instead:
- *   nbe_brick_encode   runs the level-0 encoder on the brick and writes its first / last 22 down_l0 planes to send_lo /
- *                      send_hi (device buffers of nbe_brick_halo_bytes each; opaque 16-byte units);
- *   (the caller sends send_lo to its z-minus neighbour and send_hi to its z-plus neighbour, and receives their send_hi /
- *    send_lo as recv_lo / recv_hi -- torch.distributed P2P = RCCL over xGMI in jax_nbody_emulator_with_dj_amd/sharding.py)
- *   nbe_brick_finish   runs levels 1-3 and the level-0 decoder and writes the brick's (C, b0, S1, S2) fields.
- * Both calls are asynchronous on the context's stream.  The result is bit-identical to the single-device
- * nbe_process_box of the whole box.  b0 must be a multiple of 8 and at least 44. */
-int64_t nbe_brick_halo_bytes(nbe_ctx* ctx, const int64_t brick_size[3]);
+/* Brick mode of a sharded box (no reference counterpart: the reference's loop is serial on one device, subbox.py:195-215).
+ * The ranks of a node cut the periodic box into slabs along z; a brick is periodic in y and x by itself.  What the network
+ * needs from the z neighbours is EXCHANGED at the three places where it is smallest, instead of being recomputed from a
+ * 48-plane halo of the raw input:
+ *   which 0   8 planes of the raw input per side -- the level-0 encoder's reach beyond the brick ((C, 8, S1, S2) float32);
+ *   which 1   6 planes of the down_l0 output per side -- what conv_l1 reads beyond the brick for the level-1 skip connection;
+ *   which 2   10 planes of the down_l1 output per side -- what levels 2 and 3 read.
+ * nbe_brick_halo_bytes(ctx, brick_size, which) sizes one such face (device buffers, opaque 16-byte units for 1 and 2).
+ *   nbe_brick_encode    haloed_brick = (C, b0 + 16, S1, S2): level-0 encoder; writes the first / last 6 down_l0 planes to
+ *                       send_lo / send_hi;
+ *   nbe_brick_interior  the part of conv_l1 that needs the brick's own planes only -- it runs while the faces travel;
+ *   nbe_brick_exchange  with the neighbours' faces (recv_lo = the z-minus neighbour's send_hi, recv_hi = the z-plus
+ *                       neighbour's send_lo): the rest of conv_l1, the skip connection, down_l1; writes the first / last
+ *                       10 down_l1 planes to send2_lo / send2_hi;
+ *   nbe_brick_finish    with the neighbours' second faces: levels 2-3, the decoders, the brick's (C, b0, S1, S2) fields.
+ * The four calls must follow each other on one context (any other call in between invalidates the brick and the next
+ * brick call fails); all are asynchronous on the context's stream -- the caller orders the exchanges against it (events).
+ * EVERY RANK MUST USE THE SAME RANGE SHIFT: call nbe_set_input_range with the box-wide max |x| first (the shim all-reduces
+ * it).  Fields equal the single-device nbe_process_box of the whole box: bit for bit on the direct kernels (NBE_WINO=0) and
+ * whenever slab starts pair the planes alike, else to float32 rounding (conv_h3w_kernel pairs planes from the first plane of
+ * a launch).  b0 must be a multiple of 8, at least 48.  nbe_brick_plan returns the planes per z-slab the brick would run
+ * with on the memory that is free now, or 0 when it does not fit (the caller then takes nbe_process_region). */
+int64_t nbe_brick_halo_bytes(nbe_ctx* ctx, const int64_t brick_size[3], int which);
+int nbe_brick_plan(nbe_ctx* ctx, const int64_t brick_size[3]);
 int nbe_brick_encode(nbe_ctx* ctx, const void* haloed_brick, const int64_t brick_size[3], float Dz, float vel_fac,
                      void* send_lo, void* send_hi);
-int nbe_brick_finish(nbe_ctx* ctx, const void* recv_lo, const void* recv_hi, float Dz, float vel_fac,
+int nbe_brick_interior(nbe_ctx* ctx);
+int nbe_brick_exchange(nbe_ctx* ctx, const void* recv_lo, const void* recv_hi, void* send2_lo, void* send2_hi);
+int nbe_brick_finish(nbe_ctx* ctx, const void* recv2_lo, const void* recv2_hi, float Dz, float vel_fac,
                      void* disp, void* vel, int out_dtype);
 
 /* Internal tiling.  When crop_size = size/ndiv is a multiple of 8 on every axis, all crop origins keep the

@@ -97,6 +97,11 @@ struct Layer {
     float* bias_f = nullptr;                      // conv_1: (b_1 + b_s) * act_scale (device, padded like pw.bias)
 };
 
+// pad > 0: the tensor carries a periodic halo of `pad` voxels in y and x around its interior (periodic-yx mode)
+// org: index, in the frame of the tensor the oracle forms for this layer on the tile's padded input, of the interior
+// voxel (0, 0, 0) -- only the branch probe reads it (whole tensors of a padded tile: all zero)
+struct Tensor { Planes p; int64_t off = -1; int pad = 0; int org[3] = {0, 0, 0}; };
+
 struct ProfEntry { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
 
 // Progress reports that do not stall the stream.  The reference's process_box shows a tqdm bar by default
@@ -163,13 +168,13 @@ struct nbe_ctx {
     bool zx = false;
     int phase = 0;                                // 0: whole schedule; 1: up to the exchange; 2: from the exchange on
     struct BrickIO { void *send_lo = nullptr, *send_hi = nullptr; const void *recv_lo = nullptr, *recv_hi = nullptr; } bio;
-    struct StreamState {                          // what phase 2 resumes with (handles into the arena, which is left alone in between)
+    struct StreamState {                          // what the next brick call resumes with (tensors in the arena, which is left alone in between)
         bool valid = false;
-        int64_t skip0_off = -1, td_off = -1, tin_off = -1;
-        Planes skip0, td, tin; int skip0_pad = 0, tin_pad = 0;
+        int stage = 0;                            // the last phase that ran (1 encode, 2 interior, 3 edges)
+        Tensor skip0, td, tin, t, h, y1, cat1, t2;
         int D = 0, H = 0, W = 0, S = 0;
         std::vector<Arena::Blk> blks; int64_t high = 0;
-        float Dz = 0.f, vel_fac = 0.f, act_scale = 1.f; const char* ws = nullptr;   // what nbe_brick_finish must be called with
+        float Dz = 0.f, vel_fac = 0.f, act_scale = 1.f; const char* ws = nullptr;   // what the later calls must be made with
     } sst;
     // progress inside a tile (z-slab schedule): tile k of n, reported in thousandths of a tile
     nbe_progress_cb prog_cb = nullptr; void* prog_user = nullptr; int prog_k = 0, prog_n = 1;
@@ -179,6 +184,7 @@ struct nbe_ctx {
     bool gauge = false;                           // the loaded network is wired for gauged tangents (style weights, velocity)
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
     bool fuse = false;                            // ... and the blocks' skips run fused into their conv_1 (f16x3 only)
+    bool novel_fuse = false;                      // displacement-only f16x3: the blocks are wired for conv_h3w_kernel<SKIP, NOVEL>
     int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
     // Winograd-z form of the gauged 3x3x3 layers (conv_h3w_kernel): packed beside pw.w for every gauged wide layer;
     // wino_ok is cleared when a weight of the current modulation leaves the f16 range at the kernel's 2^14 scale
@@ -375,10 +381,6 @@ static Planes ws_planes(nbe_ctx* c, int G, int D, int H, int W, int64_t* off_out
     return p;
 }
 
-// pad > 0: the tensor carries a periodic halo of `pad` voxels in y and x around its interior (periodic-yx mode)
-// org: index, in the frame of the tensor the oracle forms for this layer on the tile's padded input, of the interior
-// voxel (0, 0, 0) -- only the branch probe reads it (whole tensors of a padded tile: all zero)
-struct Tensor { Planes p; int64_t off = -1; int pad = 0; int org[3] = {0, 0, 0}; };
 static Tensor talloc(nbe_ctx* c, int C, int D, int H, int W) {
     Tensor t;
     t.p = ws_planes(c, planes_for(C, c->prec), D, H, W, &t.off);
@@ -494,6 +496,7 @@ static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 =
     return b;
 }
 
+static bool wino_env_off() { return getenv("NBE_WINO") && atoi(getenv("NBE_WINO")) == 0; }   // A/B switch, read per launch
 static bool narrow_off() { return getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0; }   // A/B switch (set before the context is created)
 static bool narrow_tile(const Layer* L) { return L->pwn.w && !narrow_off(); }
 
@@ -505,19 +508,20 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
     static const int dbgf = getenv("NBE_DEBUG_FLAGS") ? atoi(getenv("NBE_DEBUG_FLAGS")) & 0xF00 : 0;
     cl.flags |= dbgf;
     const bool g6 = c->gauge_active && L.g6 && has_dx;
+    const bool nov = !c->vel && c->prec == PREC_F16X3 && L.kind == 0 && L.pw.ww && c->wino_ok;   // displacement only: conv_h3w_kernel<., NOVEL>
     if (c->gauge_active) { cl.gout = L.gout; cl.beta = g6 ? L.beta : nullptr; }
     if (cl.skw) {                                                // the block's skip runs inside this launch
-        if (!(g6 && c->fuse && L.fskip)) return fail("internal error: fused skip requested for %s/%s", L.block.c_str(), L.layer.c_str());
+        if (!((g6 || nov) && c->fuse && L.fskip)) return fail("internal error: fused skip requested for %s/%s", L.block.c_str(), L.layer.c_str());
         cl.bias = L.bias_f;
     }
     const PackedW& pw = (g6 && L.kind == 0 && narrow_tile(&L)) ? L.pwn : L.pw;
     // Winograd along z (conv_h3w_kernel): gauged wide 3x3x3 launches without a fused skip or residual, on an even number
     // of output planes (the conditions of launch_h3w).  NBE_WINO=0 is the A/B switch (read per launch: tests flip it).
-    cl.wino = g6 && c->wino_ok && &pw == &L.pw && pw.ww && (!cl.skw || cl.skw->ww) && !(cl.flags & F_RES) && (cl.Dv & 1) == 0 && cl.in_off == 0 &&
-              cl.osz == 1 && !(getenv("NBE_WINO") && atoi(getenv("NBE_WINO")) == 0);
+    cl.wino = (g6 || nov) && c->wino_ok && &pw == &L.pw && pw.ww && (!cl.skw || cl.skw->ww) && !(cl.flags & F_RES) && (cl.Dv & 1) == 0 && cl.in_off == 0 &&
+              cl.osz == 1 && !wino_env_off();
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
-        std::string pn = cl.wino ? std::string("conv_h3w<FLAT3,vel,dx>") : conv_name(pw, c->vel, has_dx, g6, cl.set < 0);
+        std::string pn = cl.wino ? std::string(c->vel ? "conv_h3w<FLAT3,vel,dx>" : "conv_h3w<FLAT3,novel>") : conv_name(pw, c->vel, has_dx, g6, cl.set < 0);
         static const bool per_layer = getenv("NBE_PROF_LAYERS") && atoi(getenv("NBE_PROF_LAYERS")) == 1;   // tools: one entry per layer
         if (per_layer) pn += " " + L.block + "/" + L.layer;
         pe = prof_entry(c, pn);
@@ -536,7 +540,7 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
         const int taps = L.kind == 0 ? 27 : L.kind == 2 ? 8 : 1;
         const double gemms = c->vel ? ((has_dx && !g6) ? 3.0 : 2.0) : 1.0;
         c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.cin * taps * gemms;
-        if (cl.skw) c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.fskip->cin * ((cl.flags & F_SKIP_NODX) ? 2.0 : 3.0);   // W_s.x, [W_s.dx,] dW_s.x
+        if (cl.skw) c->prof_entries[pe].flops += 2.0 * nout * L.cout * L.fskip->cin * (!c->vel ? 1.0 : (cl.flags & F_SKIP_NODX) ? 2.0 : 3.0);   // W_s.x, [W_s.dx,] dW_s.x
         c->prof_entries[pe].launches += 1;
         if (c->pending.size() > 4096) prof_collect(c);
     }
@@ -557,7 +561,8 @@ static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer)
 // and writes the interior of a tensor of the same padded size, whose halo is filled afterwards; z shrinks as always.
 // (dst: write the block's result there -- a view with the result's geometry -- instead of allocating it)
 // (has_dx false: conv_l00, whose skip reads the input field -- fused with F_SKIP_NODX)
-static bool block_fused(nbe_ctx* c, const Layer* L1, bool) { return c->fuse && L1->fskip != nullptr; }
+// (displacement only: conv_h3w_kernel<SKIP, NOVEL> is the one kernel that runs a fused skip without a tangent)
+static bool block_fused(nbe_ctx* c, const Layer* L1, bool) { return c->fuse && L1->fskip != nullptr && (c->vel || !wino_env_off()); }
 
 // hidden tensor of a block whose input x has `pad`: interior (Hi - sy) x (Wi - sy).  A fused block gives it the row
 // and plane pitch of x (conv_h3g_kernel fetches the skip's patches of x with the offsets of its own input's).
@@ -574,7 +579,9 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     const int D = x.p.D, H = x.p.H, W = x.p.W, pad = x.pad;
     const int Hi = H - 2 * pad, Wi = W - 2 * pad;                 // interior of x (pad = 0: all of it)
     const int sy = pad ? 0 : 2;                                  // what one 3x3x3 convolution takes off y and x
-    const bool fused = block_fused(c, L1, has_dx);
+    // (displacement only: the fused skip exists in conv_h3w_kernel alone, which pairs planes -- an odd number of result planes,
+    // the 5 planes of conv_c behind a 104-voxel input, takes the unfused path)
+    const bool fused = block_fused(c, L1, has_dx) && (c->vel || (D & 1) == 0);
     // Unfused: the second convolution adds the skip as a residual and writes its result over it (every lane reads its
     // residual elements before it stores the same elements): one full-resolution tensor pair less at the workspace peak.
     // Fused (gauged f16x3): conv_1 computes the skip itself from x -- no skip launch, no residual round trip.
@@ -956,22 +963,6 @@ static int pipe_output(nbe_ctx* c, int z, int n, int a1 = 0, int a2 = 0, int e1 
 // 48-voxel periodic padding, without computing the halo voxels (about 10 % of the FLOPs of a 512^3 box).  The levels
 // below keep the padded scheme: down_l0 runs on the interior and its output is extended periodically by the 22
 // voxels of context those levels consume; up_r0 takes the centre of the level-1 result.
-// 22 planes of down_l0 output in an exchange buffer: [x planes][dx planes], each G plane groups of 22 x H x W units
-static constexpr int BRICK_HALO = 22;
-static Planes brick_planes(nbe_ctx* c, const Tensor& td, const void* buf) {
-    Planes p = td.p;
-    p.D = BRICK_HALO;
-    p.pstride = (p.vox() + 63) & ~int64_t(63);
-    p.x = (float*)buf;
-    p.dx = c->vel ? (float*)buf + (int64_t)p.G * p.pstride * 4 : nullptr;
-    return p;
-}
-static int64_t brick_halo_bytes(nbe_ctx* c, int Hd, int Wd) {
-    Planes p; p.G = planes_for(c->mid, c->prec); p.D = BRICK_HALO; p.H = Hd; p.W = Wd;
-    p.pstride = (p.vox() + 63) & ~int64_t(63);
-    return (int64_t)p.G * p.pstride * 16 * (c->vel ? 2 : 1);
-}
-
 static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, Tensor* skip0_out, Tensor* td_out) {
     const int m = c->mid, pad = tin.pad;
     const int D = tin.p.D, H = tin.p.H, W = tin.p.W;
@@ -1061,35 +1052,23 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
     return 0;
 }
 
-// Everything after the level-0 encoder: levels 1-3, then the level-0 decoder slab by slab with the head.
-static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, Tensor skip0, Tensor td) {
-    const int m = c->mid, pad = tin.pad;
-    const int D = tin.p.D, H = tin.p.H, W = tin.p.W;
-    const int Hi = H - 2 * pad, Wi = W - 2 * pad;
-    const bool zx = pad && c->zx;
-    const bool pz = pad && (c->pz || zx);
-    const int sy = pad ? 0 : 2;
-    const Layer *Lr00 = find_layer(c, "conv_r00", "conv_1"), *Lr01 = find_layer(c, "conv_r01", "conv_1");
-    if (!Lr00 || !Lr01) return fail("missing conv_1 layers of the level-0 blocks");
-    (void)D; (void)Hi; (void)Wi;
-    // Level 1.  Periodic-yx: it runs periodic in y and x as well -- its input is the interior result of down_l0 with a
-    // 1-voxel wrap-around halo (and, periodic in z, 22 planes of periodic context); level 2 and below keep the padded
-    // scheme: down_l1 runs on the interior and is extended periodically by the 10 voxels those levels consume.
+// Level 1 of the encoder outside brick mode: the down_l0 output td -> the level-1 skip connection cat1 (first half of the
+// decoder's concat) and the level-2 input t.
+// Periodic-yx: level 1 runs periodic in y and x as well -- its input is the interior result of down_l0 with a 1-voxel
+// wrap-around halo (and, periodic in z, 22 planes of periodic context); level 2 and below keep the padded scheme: down_l1
+// runs on the interior and is extended periodically by the 10 voxels those levels consume.
+static int stream_level1(nbe_ctx* c, int pad, bool pz, Tensor td, Tensor* cat1_out, Tensor* t_out) {
+    const int m = c->mid;
     Tensor t = td;
     if (pad) {
         t = tallocp(c, m, td.p.D + (pz ? 44 : 0), td.p.H, td.p.W, 1);
         if (t.off < 0) return fail("workspace exhausted (level 1 input)");
-        if (zx && !c->dry) {
-            // brick: own planes in the middle, the neighbours' boundary planes (received between the two calls) around them
-            launch_wrap_pad(td.p, zview(t, 22, td.p.D).p, 1, c->vel, c->stream, 0);
-            launch_wrap_pad(brick_planes(c, td, c->bio.recv_lo), zview(t, 0, 22).p, 1, c->vel, c->stream, 0);
-            launch_wrap_pad(brick_planes(c, td, c->bio.recv_hi), zview(t, 22 + td.p.D, 22).p, 1, c->vel, c->stream, 0);
-        } else if (!c->dry) launch_wrap_pad(td.p, t.p, 1, c->vel, c->stream, pz ? 22 : 0);
+        if (!c->dry) launch_wrap_pad(td.p, t.p, 1, c->vel, c->stream, pz ? 22 : 0);
         set_org(t, pz ? td.org[0] - 22 : td.org[0], td.org[1], td.org[2]);
         tfree(c, td);
     }
 
-    Tensor y1, y2, cat1, cat2, r;
+    Tensor y1, cat1;
     if (resblock(c, "conv_l1", t, true, true, m, m, &y1)) return 1;
     tfree(c, t);
     if (pad) {
@@ -1119,6 +1098,110 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
         if (downblock(c, "down_l1", y1, &t)) return 1;
     }
     tfree(c, y1);
+    *cat1_out = cat1; *t_out = t;
+    return 0;
+}
+
+// ---- brick mode (one rank's z-slab of a periodic box; include/nbe.h, "Brick mode") --------------------------------------
+// What a brick needs from its z neighbours below the full-resolution level is exchanged instead of recomputed, at the two
+// places where it is smallest: BRICK_H1 planes of the down_l0 output per side (what conv_l1 reads beyond the brick's own
+// planes for the level-1 skip connection: 4 + 2) and BRICK_H2 planes of the down_l1 output (what levels 2 and 3 read: 10).
+// Own planes of the level-1 input sit at [BRICK_H1, BRICK_H1 + B) of t.
+static constexpr int BRICK_H1 = 6, BRICK_H2 = 10;
+static Planes brick_planes(nbe_ctx* c, const Tensor& like, const void* buf, int nplanes) {
+    Planes p = like.p;
+    p.D = nplanes;
+    p.pstride = (p.vox() + 63) & ~int64_t(63);
+    p.x = (float*)buf;
+    p.dx = c->vel ? (float*)buf + (int64_t)p.G * p.pstride * 4 : nullptr;
+    return p;
+}
+static int64_t brick_halo_bytes(nbe_ctx* c, int nplanes, int Hd, int Wd) {
+    Planes p; p.G = planes_for(c->mid, c->prec); p.D = nplanes; p.H = Hd; p.W = Wd;
+    p.pstride = (p.vox() + 63) & ~int64_t(63);
+    return (int64_t)p.G * p.pstride * 16 * (c->vel ? 2 : 1);
+}
+
+// conv_l1 on plane ranges of the whole level-1 tensors (resblock_part): part 0 = what depends on the brick's own planes only,
+// part 1 = the planes next to the low face, part 2 = next to the high face
+static int brick_conv_l1(nbe_ctx* c, const Tensor& t, const Tensor& h, const Tensor& y1, int part) {
+    const int B = t.p.D - 2 * BRICK_H1;
+    if (part == 0) return resblock_part(c, "conv_l1", t, h, y1, BRICK_H1, B - 4, BRICK_H1, B - 2, true, true);
+    if (part == 1) return resblock_part(c, "conv_l1", t, h, y1, 0, BRICK_H1, 0, BRICK_H1, true, true);
+    return resblock_part(c, "conv_l1", t, h, y1, B + 2, BRICK_H1, B + 4, BRICK_H1, true, true);
+}
+
+// After the encoder: the level-1 tensors, the brick's own planes of the level-1 input, and the part of conv_l1 that needs
+// nothing from the neighbours -- it runs while the faces travel.
+static int brick_interior(nbe_ctx* c, nbe_ctx::StreamState& st) {
+    const int m = c->mid;
+    const Tensor& td = st.td;
+    const Layer* L1 = find_layer(c, "conv_l1", "conv_1");
+    if (!L1) return fail("missing layer conv_l1/conv_1");
+    st.t = tallocp(c, m, td.p.D + 2 * BRICK_H1, td.p.H, td.p.W, 1);
+    if (st.t.off < 0) return fail("workspace exhausted (level 1 input)");
+    st.h = alloc_hidden(c, m, st.t.p.D - 2, st.t, block_fused(c, L1, true));
+    st.y1 = tallocp(c, m, st.t.p.D - 4, td.p.H, td.p.W, 1);
+    if (st.h.off < 0 || st.y1.off < 0) return fail("workspace exhausted (level 1)");
+    if (!c->dry) launch_wrap_pad(td.p, zview(st.t, BRICK_H1, td.p.D).p, 1, c->vel, c->stream, 0);
+    return brick_conv_l1(c, st.t, st.h, st.y1, 0);
+}
+
+// With the neighbours' faces: the rest of conv_l1, the level-1 skip connection, down_l1 on the brick's own planes, and its
+// boundary planes for the second exchange.
+static int brick_edges(nbe_ctx* c, nbe_ctx::StreamState& st) {
+    const int m = c->mid;
+    Tensor& td = st.td;
+    const int B = td.p.D;
+    if (!c->dry) {
+        launch_wrap_pad(brick_planes(c, td, c->bio.recv_lo, BRICK_H1), zview(st.t, 0, BRICK_H1).p, 1, c->vel, c->stream, 0);
+        launch_wrap_pad(brick_planes(c, td, c->bio.recv_hi, BRICK_H1), zview(st.t, BRICK_H1 + B, BRICK_H1).p, 1, c->vel, c->stream, 0);
+    }
+    if (brick_conv_l1(c, st.t, st.h, st.y1, 1) || brick_conv_l1(c, st.t, st.h, st.y1, 2)) return 1;
+    tfree(c, st.h); tfree(c, st.t); tfree(c, td);
+    Tensor& y1 = st.y1;                                           // planes [-4, B + 4) of the brick's level-1 encoder output
+    st.cat1 = tallocp(c, 2 * m, y1.p.D, y1.p.H - 2, y1.p.W - 2, 1);
+    if (st.cat1.off < 0) return fail("workspace exhausted (cat1)");
+    if (!c->dry) {
+        Planes sp = y1.p; sp.G = c->mid / (c->prec == PREC_F16 ? 8 : 4);
+        launch_crop(sp, 0, st.cat1.p, 0, c->vel, c->stream, 0);
+    }
+    st.t2 = talloc(c, m, B / 2, (y1.p.H - 2) / 2, (y1.p.W - 2) / 2);
+    const Layer* Ld1 = find_layer(c, "down_l1", "conv_0");
+    if (st.t2.off < 0 || !Ld1) return fail("workspace exhausted or missing layer (down_l1)");
+    ConvLaunch cl; cl.in = inner(zview(y1, 4, B)); cl.Dv = st.t2.p.D; cl.Hv = st.t2.p.H; cl.Wv = st.t2.p.W; cl.out = st.t2.p; cl.flags = F_ACT;
+    if (run_conv(c, *Ld1, cl, true)) return 1;
+    tfree(c, y1);
+    if (!c->dry && c->bio.send_lo) {
+        launch_crop(zview(st.t2, 0, BRICK_H2).p, 0, brick_planes(c, st.t2, c->bio.send_lo, BRICK_H2), 0, c->vel, c->stream, 0);
+        launch_crop(zview(st.t2, st.t2.p.D - BRICK_H2, BRICK_H2).p, 0, brick_planes(c, st.t2, c->bio.send_hi, BRICK_H2), 0, c->vel, c->stream, 0);
+    }
+    return 0;
+}
+
+// The level-2 input: the brick's own down_l1 planes between the neighbours' (second exchange), extended periodically by 10
+// voxels in y and x.
+static int brick_level2(nbe_ctx* c, nbe_ctx::StreamState& st, Tensor* t_out) {
+    Tensor& t2 = st.t2;
+    Tensor t = talloc(c, c->mid, t2.p.D + 2 * BRICK_H2, t2.p.H + 20, t2.p.W + 20);
+    if (t.off < 0) return fail("workspace exhausted (level 2 input)");
+    if (!c->dry) {
+        launch_wrap_pad(t2.p, zview(t, BRICK_H2, t2.p.D).p, 10, c->vel, c->stream, 0);
+        launch_wrap_pad(brick_planes(c, t2, c->bio.recv_lo, BRICK_H2), zview(t, 0, BRICK_H2).p, 10, c->vel, c->stream, 0);
+        launch_wrap_pad(brick_planes(c, t2, c->bio.recv_hi, BRICK_H2), zview(t, BRICK_H2 + t2.p.D, BRICK_H2).p, 10, c->vel, c->stream, 0);
+    }
+    tfree(c, t2);
+    *t_out = t;
+    return 0;
+}
+
+// Everything from the level-2 input on: levels 2-3, the level-1 decoder, then the level-0 decoder slab by slab with the head.
+static int stream_tail(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, Tensor skip0, Tensor cat1, Tensor t) {
+    const int m = c->mid, pad = tin.pad;
+    const int sy = pad ? 0 : 2;
+    const Layer *Lr00 = find_layer(c, "conv_r00", "conv_1"), *Lr01 = find_layer(c, "conv_r01", "conv_1");
+    if (!Lr00 || !Lr01) return fail("missing conv_1 layers of the level-0 blocks");
+    Tensor y2, cat2, r;
     if (resblock(c, "conv_l2", t, true, true, m, m, &y2)) return 1;
     tfree(c, t);
     cat2 = talloc(c, 2 * m, y2.p.D - 8, y2.p.H - 8, y2.p.W - 8);
@@ -1192,31 +1275,49 @@ static int stream_rest(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
     return 0;
 }
 
+static void stash_arena(nbe_ctx* c) { c->sst.blks = c->arena.blks; c->sst.high = c->arena.high; }
+
+// phase 0: the whole schedule.  Brick mode (c->zx): 1 = encoder + faces of the down_l0 output, 2 = the interior of conv_l1,
+// 3 = with the received faces up to the faces of the down_l1 output, 4 = with those, everything else.  The arena keeps the
+// tensors in between (c->sst); any other use of the context drops them (sst.valid).
 static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S) {
-    Tensor skip0, td;
     auto& st = c->sst;
-    if (c->phase != 2) {
-        if (stream_encode(c, tin, ho, S, &skip0, &td)) return 1;
+    const int pad = tin.pad;
+    const bool zx = pad && c->zx;
+    if (c->phase >= 2) {
+        if (!st.valid || st.stage != c->phase - 1) return fail("brick calls out of order (encode, interior, exchange, finish) or the context was used in between");
+        c->arena.blks = st.blks; c->arena.high = st.high;
+    }
+    if (c->phase <= 1) {
+        if (stream_encode(c, tin, ho, S, &st.skip0, &st.td)) return 1;
+        st.tin = tin; st.S = S;
         if (c->phase == 1) {
-            // brick mode, first call: hand the boundary planes of the down_l0 output to the caller and stop; the arena
-            // keeps the skip connection, the down_l0 output and the input tensor until nbe_brick_finish resumes
+            // the boundary planes of the down_l0 output for the neighbours
             if (!c->dry) {
-                launch_crop(zview(td, 0, BRICK_HALO).p, 0, brick_planes(c, td, c->bio.send_lo), 0, c->vel, c->stream, 0);
-                launch_crop(zview(td, td.p.D - BRICK_HALO, BRICK_HALO).p, 0, brick_planes(c, td, c->bio.send_hi), 0, c->vel, c->stream, 0);
+                launch_crop(zview(st.td, 0, BRICK_H1).p, 0, brick_planes(c, st.td, c->bio.send_lo, BRICK_H1), 0, c->vel, c->stream, 0);
+                launch_crop(zview(st.td, st.td.p.D - BRICK_H1, BRICK_H1).p, 0, brick_planes(c, st.td, c->bio.send_hi, BRICK_H1), 0, c->vel, c->stream, 0);
             }
-            st.valid = true; st.skip0 = skip0.p; st.skip0_off = skip0.off; st.skip0_pad = skip0.pad;
-            st.td = td.p; st.td_off = td.off; st.tin = tin.p; st.tin_off = tin.off; st.tin_pad = tin.pad; st.S = S;
-            st.blks = c->arena.blks; st.high = c->arena.high;
+            st.valid = true; st.stage = 1; stash_arena(c);
             return 0;
         }
-    } else {
-        if (!st.valid) return fail("nbe_brick_finish without a preceding nbe_brick_encode");
-        skip0.p = st.skip0; skip0.off = st.skip0_off; skip0.pad = st.skip0_pad;
-        td.p = st.td; td.off = st.td_off;
-        c->arena.blks = st.blks; c->arena.high = st.high;
-        st.valid = false;
     }
-    return stream_rest(c, tin, ho, S, skip0, td);
+    if (!zx) {
+        Tensor cat1, t;
+        if (stream_level1(c, pad, pad && c->pz, st.td, &cat1, &t)) return 1;
+        return stream_tail(c, tin, ho, S, st.skip0, cat1, t);
+    }
+    if (c->phase == 0 || c->phase == 2) {
+        if (brick_interior(c, st)) return 1;
+        if (c->phase == 2) { st.stage = 2; stash_arena(c); return 0; }
+    }
+    if (c->phase == 0 || c->phase == 3) {
+        if (brick_edges(c, st)) return 1;
+        if (c->phase == 3) { st.stage = 3; stash_arena(c); return 0; }
+    }
+    Tensor t;
+    if (brick_level2(c, st, &t)) return 1;
+    st.valid = false;
+    return stream_tail(c, st.tin, ho, st.S, st.skip0, st.cat1, t);
 }
 
 // periodic-yx tiles: z as usual; y and x are the box itself (+ 2 halo voxels), a multiple of 8 with room for the
@@ -1364,7 +1465,7 @@ static void free_layers(nbe_ctx* c) {
     }
     c->layers.clear();
     c->bias_scale = 1.f; c->bias_max = 0.f; c->bias_dirty = true;
-    c->have_weights = false; c->modulated = false; c->gauge = false; c->gauge_active = false; c->fuse = false;
+    c->have_weights = false; c->modulated = false; c->gauge = false; c->gauge_active = false; c->fuse = false; c->novel_fuse = false; c->wino_ok = false;
 }
 
 static int kind_of(const nbe_layer_desc& d, int* kind) {
@@ -1399,21 +1500,46 @@ static const char* kBlocks[15] = {"conv_l00", "conv_l01", "down_l0", "conv_l1", 
 // Winograd-z weights of the gauged wide 3x3x3 layers (conv_h3w_kernel), from the modulated weights L.wn that are current
 static int pack_wino(nbe_ctx* c) {
     c->wino_ok = false;
-    if (!(c->gauge_active && c->prec == PREC_F16X3 && c->vel)) return 0;
+    if (!(c->prec == PREC_F16X3 && (c->vel ? c->gauge_active : true))) return 0;
     if (!c->wino_flag) HIPCHK(hipMalloc((void**)&c->wino_flag, 4));
     HIPCHK(hipMemsetAsync(c->wino_flag, 0, 4, c->stream));
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
-        if (L.pw.ww && L.g6) launch_pack_h3w(L.wn, L.cout, L.cin, L.pw.cin_pad, L.pw.ctiles, L.pw.ww, c->wino_flag, c->stream);
-        if (L.pw.ww && L.kind == 1 && L.b_sub && c->fuse) {        // a fused skip: [W_s | dW_s~] for conv_h3w_kernel<SKIP>
+        if (L.pw.ww && L.kind == 0 && (L.g6 || !c->vel)) launch_pack_h3w(L.wn, L.cout, L.cin, L.pw.cin_pad, L.pw.ctiles, L.pw.ww, c->wino_flag, c->stream);
+        if (L.pw.ww && L.kind == 1 && (c->vel ? (L.b_sub && c->fuse) : c->novel_fuse)) {   // a fused skip: [W_s | dW_s~] for conv_h3w_kernel<SKIP>
             launch_pack_h3w_skip(L.wn, L.cout, L.cin, L.pw, L.pw.ww, c->wino_flag, c->stream);
-            launch_pack_h3w_skip(L.dwn, L.cout, L.cin, L.pw, L.pw.ww + L.pw.floats, c->wino_flag, c->stream);
+            if (c->vel) launch_pack_h3w_skip(L.dwn, L.cout, L.cin, L.pw, L.pw.ww + L.pw.floats, c->wino_flag, c->stream);
         }
     }
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, c->wino_flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->wino_ok = bad == 0;
+    if (!c->vel) c->fuse = c->novel_fuse && c->wino_ok;         // displacement only: the fused skips live in the Winograd-z kernel
+    return 0;
+}
+
+// Displacement-only f16x3 networks: every block whose conv_1 has a Winograd-z form runs its 1x1x1 skip inside that launch
+// (conv_h3w_kernel<SKIP, NOVEL>), as the velocity networks do through wire_gauge
+static int wire_novel(nbe_ctx* c) {
+    c->novel_fuse = false;
+    static const bool no_fuse = getenv("NBE_FUSE") && atoi(getenv("NBE_FUSE")) == 0;            // A/B switch
+    if (c->vel || c->prec != PREC_F16X3 || no_fuse) return 0;
+    for (const char* b : kBlocks) {
+        if (!strncmp(b, "down_", 5) || !strncmp(b, "up_", 3)) continue;
+        auto i1 = c->layers.find(std::string(b) + "/conv_1"), is = c->layers.find(std::string(b) + "/skip");
+        if (i1 == c->layers.end() || is == c->layers.end()) return fail("internal: block %s", b);
+        Layer &L1 = i1->second, &Ls = is->second;
+        if (!L1.pw.ww || !Ls.pw.ww || 2 * (Ls.pw.cin_pad / 16) > 16 || L1.pw.ctiles != Ls.pw.ctiles) return 0;   // all blocks or none
+    }
+    for (const char* b : kBlocks) {
+        if (!strncmp(b, "down_", 5) || !strncmp(b, "up_", 3)) continue;
+        Layer &L1 = c->layers[std::string(b) + "/conv_1"], &Ls = c->layers[std::string(b) + "/skip"];
+        L1.fskip = &Ls;
+        const int nb = L1.pw.ctiles * 32 * L1.pw.ni;
+        HIPCHK(hipMalloc((void**)&L1.bias_f, nb * 4));
+    }
+    c->novel_fuse = true;
     return 0;
 }
 
@@ -1621,9 +1747,9 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             if (L.kind == 1) HIPCHK(hipMalloc((void**)&pn.dw, pn.floats * 4));   // a skip that runs inside the narrow conv_1
         }
         // Winograd-z packing (conv_h3w_kernel): 4 transformed kernels per 3 dz slices, wide tile only, Cin <= 128
-        if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && !L.first && !L.pwn.w && pw.cin_pad / 16 <= 8)
+        if (c->prec == PREC_F16X3 && L.kind == 0 && !L.first && !L.pwn.w && pw.cin_pad / 16 <= 8)
             HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
-        if (c->prec == PREC_F16X3 && c->vel && L.kind == 1 && !L.pwn.w && pw.cin_pad / 16 <= 8)     // a skip that may run fused: W_s and dW_s~
+        if (c->prec == PREC_F16X3 && L.kind == 1 && !L.pwn.w && pw.cin_pad / 16 <= 8)     // a skip that may run fused: W_s and dW_s~
             HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 2 * 4));
         // the first layer in its own packing (stem_h3_kernel): K = 27 taps x 3 channels = 81 <= 96
         if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && L.first && d.cin <= 3 && d.cout <= 64)
@@ -1665,6 +1791,10 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
     c->mod_Om = NAN; c->mod_Dz = NAN;
     const char* ge = getenv("NBE_GAUGE");
     if (c->vel && !(ge && atoi(ge) == 0)) return style ? wire_gauge(c) : wire_gauge_premod(c, descs, n);
+    if (!c->vel) {
+        if (wire_novel(c)) return 1;
+        if (!style) return pack_wino(c);                         // premodulated weights are final: pack their Winograd-z form now
+    }
     return 0;
 }
 
@@ -2284,13 +2414,14 @@ int nbe_host_trim(void) {
     return 0;
 }
 
-// ---- brick mode: one rank's z-slab of a periodic box, level-1 context exchanged instead of recomputed ---------------
-static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* W) {
+// ---- brick mode: one rank's z-slab of a periodic box, the context below the full-resolution level exchanged ---------
+static constexpr int BRICK_RAW = 8;      // planes of RAW input a brick needs from either z neighbour (the level-0 encoder's reach)
+static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* W, int64_t* need_out = nullptr) {
     c->sst.valid = false;
     if (require_ready(c)) return 1;
     if (!bsize) return fail("null argument");
     const int64_t b0 = bsize[0], S1 = bsize[1], S2 = bsize[2];
-    if (b0 % 8 != 0 || b0 / 2 < BRICK_HALO) return fail("brick depth %lld unsupported: a multiple of 8, at least %d", (long long)b0, 2 * BRICK_HALO);
+    if (b0 % 8 != 0 || b0 < 48) return fail("brick depth %lld unsupported: a multiple of 8, at least 48", (long long)b0);
     *D = (int)b0 + 96; *H = (int)S1 + 2; *W = (int)S2 + 2;
     if (check_dims_pyx(*D, *H, *W)) return 1;
     HIPCHK(hipSetDevice(c->device));
@@ -2300,27 +2431,47 @@ static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* 
     const int sl = choose_slab(c, *D, *H, *W, budget < 0 ? INT64_MAX / 4 : budget, &need, true, false);
     if (sl <= 0) { c->zx = false; return fail("brick of %lld x %lld x %lld does not fit the device memory that is free", (long long)b0, (long long)S1, (long long)S2); }
     c->slab = sl; c->pyx = true; c->pz = false;
+    if (need_out) *need_out = need;
     return 0;
 }
 
-int64_t nbe_brick_halo_bytes(nbe_ctx* c, const int64_t bsize[3]) {
-    if (!c || !bsize) return -1;
-    return brick_halo_bytes(c, (int)bsize[1] / 2, (int)bsize[2] / 2);
+int64_t nbe_brick_halo_bytes(nbe_ctx* c, const int64_t bsize[3], int which) {
+    if (!c || !bsize || which < 0 || which > 2) return -1;
+    if (which == 0) return (int64_t)c->in_chan * BRICK_RAW * bsize[1] * bsize[2] * 4;       // raw input planes, float32
+    if (which == 1) return brick_halo_bytes(c, BRICK_H1, (int)bsize[1] / 2, (int)bsize[2] / 2);
+    return brick_halo_bytes(c, BRICK_H2, (int)bsize[1] / 4, (int)bsize[2] / 4);
 }
+
+// > 0: the brick fits the device memory that is free now, with that many planes per z-slab; 0: it does not (no error)
+int nbe_brick_plan(nbe_ctx* c, const int64_t bsize[3]) {
+    if (!c || !bsize) return 0;
+    int D, H, W;
+    const int keep_slab = c->slab; const bool kp = c->pyx, kz = c->pz;
+    const int rc = brick_setup(c, bsize, &D, &H, &W);
+    const int sl = rc ? 0 : c->slab;
+    c->zx = false; c->slab = keep_slab; c->pyx = kp; c->pz = kz;
+    (void)nbe_last_error();
+    return sl;
+}
+
+struct BrickOff { nbe_ctx* c; ~BrickOff() { c->phase = 0; c->zx = false; } };
 
 int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float Dz, float vel_fac, void* send_lo, void* send_hi) {
     if (!c || !box || !send_lo || !send_hi) return fail("null argument");
     if (!is_device_ptr(box) || !is_device_ptr(send_lo) || !is_device_ptr(send_hi)) return fail("nbe_brick_encode takes device pointers");
     int D, H, W;
     if (brick_setup(c, bsize, &D, &H, &W)) return 1;
-    struct Off { nbe_ctx* c; ~Off() { c->phase = 0; c->zx = false; } } off{c};
+    BrickOff off{c};
     if (ensure_workspace(c, D, H, W)) return 1;
-    if (prepare_range(c, (const float*)box, (int64_t)c->in_chan * D * bsize[1] * bsize[2], Dz)) return 1;
+    const int Dh = (int)bsize[0] + 2 * BRICK_RAW;
+    if (prepare_range(c, (const float*)box, (int64_t)c->in_chan * Dh * bsize[1] * bsize[2], Dz)) return 1;
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W);
-    tin.pad = 1;
-    // the haloed brick is (C, b0 + 96, S1, S2): z as it is (the halo planes are there), y and x periodic (origin -1)
-    launch_gather((const float*)box, c->in_chan, D, (int)bsize[1], (int)bsize[2], 0, -1, -1, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
+    tin.pad = 1; set_org(tin, 0, 48, 48);
+    // the haloed brick is (C, b0 + 16, S1, S2): planes [40, b0 + 56) of the tile's frame -- all the level-0 encoder reads (the
+    // head reads the brick's own planes); y and x periodic (origin -1)
+    launch_gather((const float*)box, c->in_chan, Dh, (int)bsize[1], (int)bsize[2], 0, -1, -1, zview(tin, 48 - BRICK_RAW, Dh).p,
+                  Dz / 6.0f * c->act_scale, c->prec, c->stream);
     c->phase = 1; c->bio.send_lo = send_lo; c->bio.send_hi = send_hi;
     c->sst.D = D; c->sst.H = H; c->sst.W = W;
     c->sst.Dz = Dz; c->sst.vel_fac = vel_fac; c->sst.act_scale = c->act_scale; c->sst.ws = c->ws;
@@ -2330,21 +2481,47 @@ int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float 
     return 0;
 }
 
+static int brick_resume(nbe_ctx* c, int phase) {
+    if (!c->sst.valid) return fail("brick call without a preceding nbe_brick_encode (or another call has used this context's workspace in between)");
+    if (c->sst.ws != c->ws) return fail("the workspace was reallocated since nbe_brick_encode");
+    HIPCHK(hipSetDevice(c->device));
+    c->pyx = true; c->pz = false; c->zx = true; c->phase = phase;
+    return 0;
+}
+
+int nbe_brick_interior(nbe_ctx* c) {
+    if (!c) return fail("null context");
+    if (brick_resume(c, 2)) return 1;
+    BrickOff off{c};
+    const HeadOut ho{};
+    if (network_stream(c, c->sst.tin, ho, c->sst.S)) return 1;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int nbe_brick_exchange(nbe_ctx* c, const void* recv_lo, const void* recv_hi, void* send2_lo, void* send2_hi) {
+    if (!c || !recv_lo || !recv_hi || !send2_lo || !send2_hi) return fail("null argument");
+    if (brick_resume(c, 3)) return 1;
+    BrickOff off{c};
+    c->bio.recv_lo = recv_lo; c->bio.recv_hi = recv_hi; c->bio.send_lo = send2_lo; c->bio.send_hi = send2_hi;
+    const HeadOut ho{};
+    if (network_stream(c, c->sst.tin, ho, c->sst.S)) return 1;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int nbe_brick_finish(nbe_ctx* c, const void* recv_lo, const void* recv_hi, float Dz, float vel_fac, void* disp, void* vel, int out_dtype) {
     if (!c || !recv_lo || !recv_hi || !disp) return fail("null argument");
     if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
-    if (!c->sst.valid) return fail("nbe_brick_finish without a preceding nbe_brick_encode (or another call has used this context's workspace in between)");
-    if (c->sst.ws != c->ws || c->sst.Dz != Dz || c->sst.vel_fac != vel_fac || c->sst.act_scale != c->act_scale)
-        return fail("nbe_brick_finish: Dz, vel_fac and the range shift must be those of the nbe_brick_encode call it completes");
     if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
-    HIPCHK(hipSetDevice(c->device));
-    c->pyx = true; c->pz = false; c->zx = true; c->phase = 2;
-    struct Off { nbe_ctx* c; ~Off() { c->phase = 0; c->zx = false; } } off{c};
+    if (brick_resume(c, 4)) return 1;
+    BrickOff off{c};
+    if (c->sst.Dz != Dz || c->sst.vel_fac != vel_fac || c->sst.act_scale != c->act_scale)
+        return fail("nbe_brick_finish: Dz, vel_fac and the range shift must be those of the nbe_brick_encode call it completes");
     c->bio.recv_lo = recv_lo; c->bio.recv_hi = recv_hi;
-    Tensor tin; tin.p = c->sst.tin; tin.off = c->sst.tin_off; tin.pad = c->sst.tin_pad;
     const int b0 = c->sst.D - 96, S1 = c->sst.H - 2, S2 = c->sst.W - 2;
     const HeadOut ho{disp, vel, out_dtype, b0, S1, S2, 0, 0, 0, Dz, vel_fac};
-    if (network_stream(c, tin, ho, c->sst.S)) return 1;
+    if (network_stream(c, c->sst.tin, ho, c->sst.S)) return 1;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2545,6 +2722,17 @@ static int test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x,
                 TCHK(hipStreamSynchronize(c->stream));
                 c->wino_ok = bad == 0;
             }
+        }
+        if (!vel && kind == 0 && c->prec == PREC_F16X3 && cin > 3 && pw.cin_pad / 16 <= 8) {
+            // displacement only: conv_h3w_kernel<false, NOVEL> when the output has an even number of planes (as run_conv decides)
+            TCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
+            if (!c->wino_flag) TCHK(hipMalloc((void**)&c->wino_flag, 4));
+            TCHK(hipMemsetAsync(c->wino_flag, 0, 4, c->stream));
+            launch_pack_h3w(dwt, cout, cin, pw.cin_pad, pw.ctiles, pw.ww, c->wino_flag, c->stream);
+            int bad = 0;
+            TCHK(hipMemcpyAsync(&bad, c->wino_flag, 4, hipMemcpyDeviceToHost, c->stream));
+            TCHK(hipStreamSynchronize(c->stream));
+            c->wino_ok = bad == 0;
         }
         TCHK(hipMalloc((void**)&dxin, nin * 4)); TCHK(hipMemcpy(dxin, x, nin * 4, hipMemcpyHostToDevice));
         if (has_dx) { TCHK(hipMalloc((void**)&ddx, nin * 4)); TCHK(hipMemcpy(ddx, dx, nin * 4, hipMemcpyHostToDevice)); }

@@ -2154,8 +2154,12 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     if (stem_on && ka.stem_w && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
         !(ka.flags & F_RES) && ka.nskip == 0 && !ka.beta)
         return launch_stem(ka, s);
-    // a second input segment / a fused skip exist only in the wide gauged f16x3 kernel
-    if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split)) return 1;
+    // a second input segment / a fused skip exist only in the wide gauged f16x3 kernel and in conv_h3w_kernel's displacement-only form
+    if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split)) {
+        if (split && !vel && ka.ww && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1)
+            return launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s, true);     // 1: no such form for this launch (an engine bug)
+        return 1;
+    }
 #define NBE_VD(F, ...)                                                          \
     if (vel) { if (has_dx) F<__VA_ARGS__, true, true>(ka, ct, s); else F<__VA_ARGS__, true, false>(ka, ct, s); } \
     else F<__VA_ARGS__, false, false>(ka, ct, s);
@@ -2181,6 +2185,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     const bool first_flat = l0_flat && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.nchunk == 1;
     if (pw.mode == MODE_FLAT3 && !flat3 && !first_flat && ka.in_off == 0 && ka.osz == 1) {
         if (split && vel && has_dx && !shape32 && sched == 0) return launch_h3q(ka, ct, s);
+        if (split && !vel && ka.ww && launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s, true) == 0) return 0;   // Winograd along z, displacement only
         if (split && !vel && !shape32) return launch_h2q<true>(ka, ct, s);
         if (!split && vel && has_dx && !shape32) return launch_h2q<false>(ka, ct, s);
         if (!split) { NBE_VD(launch_h3p_v, 0, false) }

@@ -55,7 +55,15 @@ struct WinoKArgs {
 // global -> LDS DMA (nothing to transform), weights [W_s | dW_s~] scaled by 2^14 like the layer's own:
 //     y += W_s.x      dy += W_s.dx~ + dW_s~.x          (dW_s~ = dW_s - W_s (.) a - beta_1 W_s, see conv_h3g_kernel)
 // on the centre tap, the K halves selecting the part: [wh | wh 2^-11] . [xh | xl] and [wl | 0] . [xh | xl].
-template <bool SKIP>
+//
+// NOVEL: the displacement-only layer (style_layers.py:86-99: y = conv(x, w) + b, no tangent) on the SAME instruction stream.
+// Without a tangent the second accumulator set and the second patch tensor are free, so they carry a second block of
+// eight output rows: "dx" is x eight rows further down (WinoSrc::dxd = 8 rows), "DY" the outputs of rows y0 + 8 .. y0 + 15.
+// A workgroup then owns 16 rows x 32 columns x 2 planes for the same weights in LDS -- half the weight stream per output,
+// which is what the one-accumulator-set form lacks (conv_h2q_kernel<SPLIT> doubles its tile for the same reason).  Only
+// the epilogue (bias and LeakyReLU for both sets, both stored to y) and the fused skip's products (W_s.x for both row
+// blocks, no dW_s~) differ.
+template <bool SKIP, bool NOVEL>
 __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     typedef HGGeom<false, true, false> G;
     constexpr int NW = 8, CT = 64, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = 4, NT = 2, NTILE = 8;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             zp = full + zi; ty = tyx / a.tnx; tx = tyx - ty * a.tnx;
         }
     }
-    const int y0 = ty * HP_ROWS, x0 = tx * HP_COLS, z0 = 2 * zp;
+    const int y0 = ty * (NOVEL ? 2 * HP_ROWS : HP_ROWS), x0 = tx * HP_COLS, z0 = 2 * zp;
     const int nst = 4 * a.nchunk;
 
     const long to = (((long)z0 * a.H + y0) * a.W + x0) * 16;
@@ -379,19 +387,21 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a1[mt] = a1[mt] * m1;
         NBE_SB; MM8(Y, a1, bx, -1, 0, false, true); NBE_SB;                               // [W_s hi | W_s hi 2^-11] . [x hi | x lo]
-        LA(d1, aS + TAPU);
+        if (!NOVEL) LA(d1, aS + TAPU);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a2[mt] = ks ? zero : a2[mt];
         NBE_SB; MM8(Y, a2, bx, -1, 0, false, true); NBE_SB;                               // [W_s lo | 0] . [x hi | x lo]
-        LA(d2, aS + TAPU + CT);
-        if (!(a.flags & F_SKIP_NODX)) {                                                  // (conv_l00: the input field has no tangent)
-            NBE_SB; MM8(DY, a1, bd, -1, 0, false); NBE_SB;
+        if (!NOVEL) LA(d2, aS + TAPU + CT);
+        if (NOVEL || !(a.flags & F_SKIP_NODX)) {                                         // (conv_l00: the input field has no tangent)
+            NBE_SB; MM8(DY, a1, bd, -1, 0, false); NBE_SB;                                // NOVEL: W_s . x of the second row block
             MM8(DY, a2, bd, -1, 0, false); NBE_SB;
         }
+        if (!NOVEL) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { d1[mt] = d1[mt] * m1; d2[mt] = ks ? zero : d2[mt]; }
-        NBE_SB; MM8(DY, d1, bx, -1, 0, false, true); NBE_SB;                              // dW_s~ . x
-        MM8(DY, d2, bx, -1, 0, false, true); NBE_SB;
+            for (int mt = 0; mt < MT; ++mt) { d1[mt] = d1[mt] * m1; d2[mt] = ks ? zero : d2[mt]; }
+            NBE_SB; MM8(DY, d1, bx, -1, 0, false, true); NBE_SB;                          // dW_s~ . x
+            MM8(DY, d2, bx, -1, 0, false, true); NBE_SB;
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // fetched per row tile the epilogue was eight rounds of (store, drain, load, wait); worth 2 % on the 64-channel layers.
     // (Builds without the stores, or without the epilogue, run a box 13-16 % faster -- but they leave every activation at the
     // workspace's zeros, and on this power-limited chip MFMAs on zeros are cheap: such probes price the data, not the stores.)
-    const bool act = a.flags & F_ACT, gauge = a.gout != nullptr;
+    const bool act = a.flags & F_ACT, gauge = !NOVEL && a.gout != nullptr;
     f32x4 bv[MT], be[MT], gv[MT];
     int unit[MT];
     bool uok[MT];
@@ -469,9 +479,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         uok[mt] = unit[mt] < a.cout_groups;
         if (!uok[mt]) unit[mt] = a.cout_groups - 1;
         bv[mt] = *(const f32x4*)(a.bias + unit[mt] * 8 + 4 * kh);
-        be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
+        be[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!NOVEL) be[mt] = *(const f32x4*)(a.beta + unit[mt] * 8 + 4 * kh);
         gv[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
+        if (!NOVEL && gauge) gv[mt] = *(const f32x4*)(a.gout + unit[mt] * 8 + 4 * kh);
     }
     // (a use of all of them here: the compiler waits for the loads now, once -- left to their first uses it waits with a count
     // that only the draining of the stores issued in between can satisfy)
@@ -479,11 +490,12 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(bv[mt]), "+v"(be[mt]), "+v"(gv[mt]));
     auto epilogue = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int z) {
         int o[NT];
-        bool ook[NT];
+        bool ook[NT], ook2[NT];                                  // NOVEL: the second row block, eight rows further down
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int yy = y0 + rowp, xx = x0 + 16 * nt + c;
             ook[nt] = yy < a.Hv && xx < a.Wv;
+            ook2[nt] = NOVEL && yy + HP_ROWS < a.Hv && xx < a.Wv;
             o[nt] = ook[nt] ? (z * a.Ho + yy) * a.Wo + xx : z * a.Ho * a.Wo;
         }
 #pragma unroll
@@ -510,6 +522,27 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
                 }
+                if (NOVEL) {                                     // two row blocks of y: bias and LeakyReLU on both sets
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dv[e] = acc_read(DY[t][e]) * a.inv_scale + bv[mt][e];
+                        if (act) dv[e] = dv[e] >= 0.f ? dv[e] : 0.01f * dv[e];
+                    }
+                    const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
+                    const long ol = ob + a.out_pstride * 16;
+                    const long r8 = (long)HP_ROWS * a.Wo * 16;
+                    half4 hi, lo;
+                    if (uok[mt] && ook[nt]) {
+                        split4(v, hi, lo);
+                        *(half4*)((char*)a.y + ob) = hi;
+                        *(half4*)((char*)a.y + ol) = lo;
+                    }
+                    if (uok[mt] && ook2[nt]) {
+                        split4(dv, hi, lo);
+                        *(half4*)((char*)a.y + ob + r8) = hi;
+                        *(half4*)((char*)a.y + ol + r8) = lo;
+                    }
+                } else
                 if (uok[mt] && ook[nt]) {
                     const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
                     const long ol = ob + a.out_pstride * 16;
@@ -567,28 +600,34 @@ void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int c
 
 // 0: launched; 1: this launch has no Winograd form (the caller falls back to conv_h3g_kernel)
 // wws: the fused skip's weights [W_s | dW_s~] in the kernel's scaling (PackedW::ww of the skip layer), needed when ka.nskip > 0
-static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, long wws_set_floats, int ctiles, hipStream_t s) {
+// novel: the displacement-only form (conv_h3w_kernel<SKIP, true>): no tangent tensors, two row blocks per workgroup
+static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, long wws_set_floats, int ctiles, hipStream_t s,
+                      bool novel = false) {
     typedef HGGeom<false, true, false> G;
     constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
-    if (!ww || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || !ka.beta) return 1;
+    if (!ww || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || (!novel && !ka.beta)) return 1;
     if (ka.nskip > 0 && (!wws || 2 * ka.nskip > NBE_MAX_WSKIP)) return 1;
     if (ctiles != (ka.cout_groups + 7) / 8) return 1;
     // the raw planes are fetched with buffer loads (32-bit offsets): lane offset + hi -> lo plane distance stay below 2^32
     if (std::max(ka.in_pstride, ka.csplit < ka.nchunk ? ka.in2_pstride : 0L) * 16 + 16L * (HP_ROWS + 2) * ka.W >= (1L << 32) - (1L << 20)) return 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     WinoKArgs wa;
     wa.H = ka.H; wa.W = ka.W; wa.Dv = ka.Dv; wa.Hv = ka.Hv; wa.Wv = ka.Wv; wa.Ho = ka.Ho; wa.Wo = ka.Wo;
     wa.nchunk = ka.nchunk; wa.cout_groups = ka.cout_groups; wa.flags = ka.flags;
-    wa.tny = (ka.Hv + HP_ROWS - 1) / HP_ROWS;
+    const int trows = novel ? 2 * HP_ROWS : HP_ROWS;
+    wa.tny = (ka.Hv + trows - 1) / trows;
     wa.tnx = (ka.Wv + HP_COLS - 1) / HP_COLS;
     wa.ntiles = (ka.Dv / 2) * wa.tny * wa.tnx;
     wa.y = ka.y; wa.dy = ka.dy; wa.out_pstride = ka.out_pstride; wa.out_g0 = ka.out_g0;
-    wa.bias = ka.bias; wa.gout = ka.gout; wa.beta = ka.beta;
+    wa.bias = ka.bias; wa.gout = novel ? nullptr : ka.gout; wa.beta = novel ? nullptr : ka.beta;
+    const long rows8 = (long)HP_ROWS * ka.W * 16;                // novel: the "tangent" patch is the input eight rows further down
     wa.inv_scale = 1.0f / WINO_WSCALE;
     {
         // A/B (profiles/r02_ab_wino_zblock.txt): 0 = all pairs of the launch (z fastest) 1494 ms per box, 1 (x fastest) 1496,
@@ -612,7 +651,7 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
                 const char* dx = (const char*)(second ? ka.dx2 : ka.dx);
                 const long off = (long)(second ? chunk - ka.csplit : chunk) * 4 * ps * 16;
                 WinoSrc& e = wa.st[(ph * ka.nchunk + chunk) * 2 + ab];
-                e.xa = x + off + PA[xi] * plane; e.xb = x + off + PB[xi] * plane; e.dxd = dx - x;
+                e.xa = x + off + PA[xi] * plane; e.xb = x + off + PB[xi] * plane; e.dxd = novel ? rows8 : dx - x;
                 e.w = (const char*)ww + (long)(chunk * 4 + xi) * G::WG * 16; e.psb = ps * 16; e.sb = SB[xi]; e.pad_ = 0;
             }
     // raw stages of the fused skip: chunk sc of the block input, plane z0 (-> A) and plane z0 + 1 (-> B); ka.xs is already
@@ -625,10 +664,14 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
             const char* dx = (const char*)(second ? ka.dxs2 : ka.dxs);
             const long off = (long)(second ? sc - ka.s_csplit : sc) * 4 * ps * 16 + ab * plane;
             WinoSrc& e = wa.st[4 * ka.nchunk + 2 * sc + ab];
-            e.xa = x + off; e.xb = e.xa; e.dxd = dx - x; e.w = (const char*)wws + (long)sc * G::TAPU * 16; e.psb = ps * 16; e.sb = 0.f; e.pad_ = 0;
+            e.xa = x + off; e.xb = e.xa; e.dxd = novel ? rows8 : dx - x; e.w = (const char*)wws + (long)sc * G::TAPU * 16; e.psb = ps * 16; e.sb = 0.f; e.pad_ = 0;
         }
     dim3 grid(wa.ntiles * ctiles, 1, 1), block(512, 1, 1);
-    if (ka.nskip > 0) hipLaunchKernelGGL(conv_h3w_kernel<true>, grid, block, smem, s, wa);
-    else hipLaunchKernelGGL(conv_h3w_kernel<false>, grid, block, smem, s, wa);
+    if (novel) {
+        wa.dws_delta = 0;
+        if (ka.nskip > 0) hipLaunchKernelGGL((conv_h3w_kernel<true, true>), grid, block, smem, s, wa);
+        else hipLaunchKernelGGL((conv_h3w_kernel<false, true>), grid, block, smem, s, wa);
+    } else if (ka.nskip > 0) hipLaunchKernelGGL((conv_h3w_kernel<true, false>), grid, block, smem, s, wa);
+    else hipLaunchKernelGGL((conv_h3w_kernel<false, false>), grid, block, smem, s, wa);
     return 0;
 }

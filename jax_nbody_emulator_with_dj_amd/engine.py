@@ -291,34 +291,52 @@ class Engine:
                                          _ptr(disp), _ptr(vel), 1 if half else 0, i64(disp.shape[1:]), i64(out_origin)))
 
     # ---- brick mode (sharded box, z-slabs with one activation exchange per box) -------------------
-    def brick_halo_bytes(self, bshape):
-        n = int(self._l.nbe_brick_halo_bytes(self._h, (C.c_int64 * 3)(*[int(v) for v in bshape])))
+    RAW_HALO = 8            # planes of raw input a brick needs from either z neighbour (include/nbe.h, "Brick mode")
+
+    def brick_halo_bytes(self, bshape, which=1):
+        """Bytes of one exchanged face: which = 0 raw input (8 planes), 1 down_l0 output (6 planes), 2 down_l1 output (10)."""
+        n = int(self._l.nbe_brick_halo_bytes(self._h, (C.c_int64 * 3)(*[int(v) for v in bshape]), int(which)))
         if n < 0:
             raise NBEError("nbe_brick_halo_bytes failed")
         return n
 
+    def brick_plan(self, bshape):
+        """Planes per z-slab the brick would run with on the memory that is free now; 0 = it does not fit."""
+        return int(self._l.nbe_brick_plan(self._h, (C.c_int64 * 3)(*[int(v) for v in bshape])))
+
+    def _check_faces(self, bshape, which, *faces):
+        n = self.brick_halo_bytes(bshape, which)
+        for t in faces:
+            if not t.is_cuda or t.numel() * t.element_size() < n:
+                raise NBEError("brick exchange buffers must be CUDA tensors of at least %d bytes" % n)
+
     def brick_encode(self, haloed, bshape, Dz, vel_fac, send_lo, send_hi):
-        """haloed: CUDA tensor (C, b0 + 96, S1, S2); send_lo / send_hi: CUDA uint8 tensors of brick_halo_bytes()."""
+        """haloed: CUDA tensor (C, b0 + 16, S1, S2); send_lo / send_hi: CUDA uint8 tensors of brick_halo_bytes(bshape, 1)."""
         self._follow_torch_stream(haloed)
         b = tuple(int(v) for v in bshape)
+        self._brick = b
         # the kernels read exactly this much: check before anything is launched
-        if tuple(haloed.shape) != (self.in_chan, b[0] + 96, b[1], b[2]) or haloed.dtype != torch.float32 or not haloed.is_contiguous():
-            raise NBEError("haloed brick must be a contiguous float32 (C, b0 + 96, S1, S2) = %s tensor; got %s %s"
-                           % ((self.in_chan, b[0] + 96, b[1], b[2]), tuple(haloed.shape), haloed.dtype))
-        n = self.brick_halo_bytes(b)
-        for t in (send_lo, send_hi):
-            if t.numel() * t.element_size() < n or not t.is_cuda:
-                raise NBEError("brick exchange buffers must be CUDA tensors of at least %d bytes" % n)
-        check(self._l.nbe_brick_encode(self._h, _ptr(haloed), (C.c_int64 * 3)(*[int(v) for v in bshape]), float(Dz),
+        want = (self.in_chan, b[0] + 2 * self.RAW_HALO, b[1], b[2])
+        if tuple(haloed.shape) != want or haloed.dtype != torch.float32 or not haloed.is_contiguous():
+            raise NBEError("haloed brick must be a contiguous float32 (C, b0 + 16, S1, S2) = %s tensor; got %s %s"
+                           % (want, tuple(haloed.shape), haloed.dtype))
+        self._check_faces(b, 1, send_lo, send_hi)
+        check(self._l.nbe_brick_encode(self._h, _ptr(haloed), (C.c_int64 * 3)(*b), float(Dz),
                                        float(vel_fac), _ptr(send_lo), _ptr(send_hi)))
 
-    def brick_finish(self, recv_lo, recv_hi, Dz, vel_fac, disp, vel):
+    def brick_interior(self):
+        check(self._l.nbe_brick_interior(self._h))
+
+    def brick_exchange(self, recv_lo, recv_hi, send2_lo, send2_hi):
+        self._check_faces(self._brick, 1, recv_lo, recv_hi)
+        self._check_faces(self._brick, 2, send2_lo, send2_hi)
+        check(self._l.nbe_brick_exchange(self._h, _ptr(recv_lo), _ptr(recv_hi), _ptr(send2_lo), _ptr(send2_hi)))
+
+    def brick_finish(self, recv2_lo, recv2_hi, Dz, vel_fac, disp, vel):
         self._follow_torch_stream(disp)
         half = disp.element_size() == 2
-        for t in (recv_lo, recv_hi):
-            if not t.is_cuda:
-                raise NBEError("brick exchange buffers must be CUDA tensors")
-        check(self._l.nbe_brick_finish(self._h, _ptr(recv_lo), _ptr(recv_hi), float(Dz), float(vel_fac), _ptr(disp),
+        self._check_faces(self._brick, 2, recv2_lo, recv2_hi)
+        check(self._l.nbe_brick_finish(self._h, _ptr(recv2_lo), _ptr(recv2_hi), float(Dz), float(vel_fac), _ptr(disp),
                                        _ptr(vel), 1 if half else 0))
 
     # ---- test hooks ---------------------------------------------------------------------------

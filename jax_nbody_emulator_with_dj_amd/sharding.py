@@ -12,17 +12,20 @@ The exchange is axis by axis (3 rounds, 2 messages per split axis) so that edges
 corners arrive through the face messages: the slab sent along axis a spans the halos
 already filled on axes < a.  Bytes per rank for 512^3 on a 2x2x2 grid: 322 MB.
 
-z-slab bricks (rank grid (N,1,1), the default whenever a slab is at least 44 planes deep).
+z-slab bricks (rank grid (N,1,1), the default whenever a slab is at least 48 planes deep).
 A brick that is not split in y and x is periodic there by itself, so only its z halo costs
-anything -- and most of that cost sits BELOW the full-resolution level: the 48-plane halo of
-the raw input exists to give levels 1-3 their 22 planes of context.  Instead of recomputing
-44 planes of level-0 work per side for it, the ranks exchange the 22 boundary planes of the
-down_l0 OUTPUT once per box (Engine.brick_encode -> P2P -> Engine.brick_finish; 738 MB per
-direction for 512^3 on 8 ranks, a few ms over xGMI against ~0.25 s of compute).  What is
-still recomputed is the level-0 halo of 4 + 4 planes (the skip connection's receptive field)
-and the 22-plane halo at level 1 (1/8 of the work per plane): 1.25 x the work of the ideal
-at 8 ranks instead of 1.45 x with 256^3 bricks.  Fields are bit-identical to the single-GPU
-run.  The four exchange buffers are allocated once per ShardedBox.
+anything -- and almost all of that cost sits BELOW the full-resolution level: the 48-plane halo of
+the raw input exists to give levels 1-3 their context.  Instead of recomputing it, the ranks
+exchange what each level needs where it is smallest (include/nbe.h, "Brick mode"): 8 planes of raw
+input per side (25 MB at 512^2), 6 planes of the down_l0 output (201 MB; the interior of conv_l1
+runs while they travel, on the communication stream), 10 planes of the down_l1 output (84 MB).
+What is still recomputed is the level-0 halo of 4 + 4 planes, 4 + 4 planes of conv_l1 and the
+10-plane halo of levels 2-3 (1.5 % of the work): 1.14 x the ideal at 8 ranks (1.25 x with one
+exchange of 22 planes, round 2; 1.45 x with padded 256^3 bricks).  The fields equal the single-GPU run
+(bit for bit on the direct kernels; to float32 rounding where the Winograd-z kernel pairs planes
+differently).  The exchange buffers are allocated once per ShardedBox.  A brick whose workspace does
+not fit the memory that is free (all ranks agree on that with a 4-byte all-reduce) falls back to the
+padded bricks below.
 """
 
 import numpy as np
@@ -37,14 +40,15 @@ except Exception:  # pragma: no cover
 PAD = 48
 
 
-BRICK_MIN_DEPTH = 44          # two times the 22 planes of level-1 context a brick hands to each neighbour
+BRICK_MIN_DEPTH = 48          # a brick hands 10 planes of its down_l1 output (a quarter of its depth) to either neighbour
+RAW_HALO = 8                  # planes of raw input a brick needs from either z neighbour
 
 
 def _zbrick_factor(e0):
-    """Work per output voxel of a z-slab brick of depth e0 with the level-1 exchange, relative to no halo at all:
-    level 0 (90 % of the FLOPs) computes ~7 extra planes, level 1 (8.5 %) 44 extra half-resolution planes, levels 2-3
-    (1.5 %) about as many again."""
-    return 1.0 + 0.90 * 7.0 / e0 + 0.085 * 44.0 / (e0 / 2.0) + 0.015 * 44.0 / (e0 / 2.0)
+    """Work per output voxel of a z-slab brick of depth e0 with the three exchanges, relative to no halo at all:
+    level 0 (90 % of the FLOPs) computes ~7 extra planes, level 1 (8.5 %) ~7 extra half-resolution planes, levels 2-3
+    (1.5 %) 20 quarter-resolution ones."""
+    return 1.0 + 0.90 * 7.0 / e0 + 0.085 * 7.0 / (e0 / 2.0) + 0.015 * 20.0 / (e0 / 4.0)
 
 
 def _halo_factor(e):
@@ -228,17 +232,62 @@ class ShardedBox:
         self.comm_stream = comm_stream
         self._halo = None                       # (send_lo, send_hi, recv_lo, recv_hi), allocated once
         self.fallback = None                    # optional strict-float32 Engine with the same parameters (see process)
+        self._agreed = False                    # the ranks have agreed on brick mode vs padded bricks (first call)
+
+    def _exchange_async(self, cur, send_lo, send_hi, recv_lo, recv_hi):
+        """Face exchange on the communication stream, behind what `cur` has enqueued so far; returns the event the consumer
+        waits for (None: the exchange ran on `cur` itself)."""
+        comm = self.comm_stream
+        if comm is None or comm == cur:
+            exchange_z_faces(send_lo, send_hi, recv_lo, recv_hi, self.coords, self.grid, self.group)
+            return None
+        comm.wait_stream(cur)
+        with torch.cuda.stream(comm):
+            exchange_z_faces(send_lo, send_hi, recv_lo, recv_hi, self.coords, self.grid, self.group)
+            ev = torch.cuda.Event()
+            ev.record(comm)
+        for t in (send_lo, send_hi, recv_lo, recv_hi):
+            t.record_stream(comm)
+        return ev
 
     def _process_zbrick(self, brick, Dz, vel_fac, disp, vel):
-        """z-slab brick with ONE exchange of level-1 activations (module docstring)."""
-        H = exchange_halo(brick, self.grid, self.coords, PAD, self.group, pad_unsplit=False)     # raw input, 48 planes in z
+        """z-slab brick: three small exchanges instead of a recomputed 48-plane halo (module docstring).  The compute stream
+        never waits for a transfer it could not have overlapped: the 6-plane faces of the down_l0 output travel under the
+        interior of conv_l1."""
+        cur = torch.cuda.current_stream(brick.device)
+        H = exchange_halo(brick, self.grid, self.coords, RAW_HALO, self.group, pad_unsplit=False)     # raw input, 8 planes in z
         if self._halo is None or self._halo[0].device != brick.device:
-            n = self.eng.brick_halo_bytes(self.bshape)
-            self._halo = tuple(torch.empty(n, dtype=torch.uint8, device=brick.device) for _ in range(4))
-        s_lo, s_hi, r_lo, r_hi = self._halo
+            n1, n2 = self.eng.brick_halo_bytes(self.bshape, 1), self.eng.brick_halo_bytes(self.bshape, 2)
+            self._halo = tuple(torch.empty(n, dtype=torch.uint8, device=brick.device) for n in (n1,) * 4 + (n2,) * 4)
+        s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi = self._halo
         self.eng.brick_encode(H, self.bshape, Dz, vel_fac, s_lo, s_hi)
-        exchange_z_faces(s_lo, s_hi, r_lo, r_hi, self.coords, self.grid, self.group)
-        self.eng.brick_finish(r_lo, r_hi, Dz, vel_fac, disp, vel)
+        ev = self._exchange_async(cur, s_lo, s_hi, r_lo, r_hi)
+        self.eng.brick_interior()                                   # runs while the faces travel
+        if ev is not None:
+            cur.wait_event(ev)
+        self.eng.brick_exchange(r_lo, r_hi, s2_lo, s2_hi)
+        ev = self._exchange_async(cur, s2_lo, s2_hi, r2_lo, r2_hi)
+        if ev is not None:
+            cur.wait_event(ev)
+        self.eng.brick_finish(r2_lo, r2_hi, Dz, vel_fac, disp, vel)
+
+    def _agree_on_bricks(self, device):
+        """A brick whose workspace does not fit the memory that is free now runs as padded bricks instead; every rank must
+        take the same path (the exchanges differ), so they agree once, with a 4-byte all-reduce."""
+        if self._agreed or not self.zbricks:
+            self._agreed = True
+            return
+        ok = 1 if self.eng.brick_plan(self.bshape) > 0 else 0
+        if self.world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if dist.get_backend(self.group) == "gloo" else device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = int(flag.item())
+        if not ok:
+            import warnings
+            warnings.warn("the z-slab brick %s does not fit the device memory that is free on every rank: falling back to padded "
+                          "bricks (more halo recompute)" % (self.bshape,), RuntimeWarning)
+            self.zbricks = False
+        self._agreed = True
 
     def backend(self):
         """'nccl' (= RCCL, device to device over xGMI) or 'gloo' (host-staged: CPU tests and one-card rigs); None for one rank."""
@@ -295,6 +344,7 @@ class ShardedBox:
 
     def _process_on(self, brick, Dz, vel_fac, disp, vel):
         cur = torch.cuda.current_stream(brick.device)
+        self._agree_on_bricks(brick.device)
         # one range shift for the whole box (include/nbe.h, "Range"): max |x| over all bricks, a 4-byte all-reduce --
         # every rank then computes its brick with the arithmetic a single-GPU run of the box would use
         amax = torch.linalg.vector_norm(brick.reshape(-1), ord=float('inf')).float().reshape(1)

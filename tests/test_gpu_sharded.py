@@ -45,7 +45,7 @@ def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q, zb=True):
         full = np.random.default_rng(seed_x).standard_normal((3,) + size).astype(np.float32)
         sb = sharding.ShardedBox(eng, size, ndiv, rank, world)
         o, b = sb.origin, sb.bshape
-        want_z = zb and sb.grid[0] > 1 and sb.grid[1] == 1 and sb.grid[2] == 1 and b[0] >= 44
+        want_z = zb and sb.grid[0] > 1 and sb.grid[1] == 1 and sb.grid[2] == 1 and b[0] >= 48
         assert sb.zbricks == want_z, (sb.grid, b, sb.zbricks)
         brick = torch.from_numpy(np.ascontiguousarray(
             full[:, o[0]:o[0] + b[0], o[1]:o[1] + b[1], o[2]:o[2] + b[2]])).cuda()
@@ -58,9 +58,9 @@ def _rank_main(rank, world, port, size, ndiv, seed_p, seed_x, q, zb=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,ndiv", [(2, (128, 64, 64), (2, 1, 1)),         # (2,1,1): 64-plane z-slab bricks, level-1 exchange
+@pytest.mark.parametrize("world,size,ndiv", [(2, (128, 64, 64), (2, 1, 1)),         # (2,1,1): 64-plane z-slab bricks, three small exchanges
                                              (4, (128, 128, 64), (4, 2, 1)),        # rank grid (2,2,1): y split, padded
-                                             (4, (256, 64, 64), (4, 1, 1)),         # (4,1,1): z-slab bricks, level-1 exchange
+                                             (4, (256, 64, 64), (4, 1, 1)),         # (4,1,1): z-slab bricks
                                              (4, (192, 48, 56), (2, 1, 1)),         # 48-plane bricks; the sub-box grid does not divide by 4
                                              (-4, (256, 64, 64), (4, 1, 1))])       # NBE_ZBRICKS=0: the padded z-slab bricks of round 1
 def test_sharded_equals_single_process(world, size, ndiv):
@@ -99,6 +99,6 @@ def test_sharded_equals_single_process(world, size, ndiv):
     np.testing.assert_allclose(v_all, v_ref, rtol=1e-5, atol=1e-4)
     from jax_nbody_emulator_with_dj_amd import sharding
     grid = sharding.rank_grid(world, ndiv, size)
-    if zb and grid[1] == 1 and grid[2] == 1 and size[0] // grid[0] >= 44:
-        # z-slab bricks with the level-1 exchange run the single-GPU schedule of the whole box, cut along z: bit for bit
+    if zb and grid[1] == 1 and grid[2] == 1 and size[0] // grid[0] >= 48:
+        # z-slab bricks run the single-GPU schedule of the whole box, cut along z, with the same pairing of planes: bit for bit
         assert np.array_equal(d_all, d_ref) and np.array_equal(v_all, v_ref)
