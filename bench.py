@@ -96,6 +96,7 @@ def main():
                          "f32: strict float32 MFMA")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-f32 reference pass")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-array (NumPy in / NumPy out) pass")
+    ap.add_argument("--no-small-configs", action="store_true", help="skip BASELINE configs 1 and 2 (128^3 cases) beside the headline")
     ap.add_argument("--no-profile", action="store_true",
                     help="no per-kernel HIP events in the timed region (no roofline object): the tiles then replay from "
                          "captured hipGraphs, which profiling turns off -- for the graph A/B (NBE_GRAPH=0 / 1)")
@@ -297,6 +298,43 @@ def main():
     if args.precision != "f32" and world == 1 and not args.no_strict:
         strict = measure("f32", 1, 1)             # the strict-float32 MFMA path on the same box, for reference
 
+    def measure_small_configs(reps=5):
+        """BASELINE configs 1 and 2 on this card, resident tensors (parity-test cases; reported beside the headline):
+        config 1 = StyleNBodyEmulatorVelCore.apply on one (1,3,128,128,128) sub-box -> 32^3;
+        config 2 = process_box 128^3, ndiv (1,1,1), compute_vel=False (the single-tile displacement-only kernel path)."""
+        out = {}
+        x = torch.randn((3, 128, 128, 128), device=dev, dtype=torch.float32, generator=gen)
+        for name, cv in (("config1", True), ("config2", False)):
+            eng = Engine(device=local_rank, compute_vel=cv, precision=args.precision)
+            eng.load_params((StyleNBodyEmulatorVelCore if cv else StyleNBodyEmulatorCore)().init(1234), premodulated=False)
+            eng.set_cosmology(OM, Dz)
+            if cv:
+                step = lambda: eng.forward(x, Dz, vf)
+                work, nvox, flop = "apply (1,3,128,128,128) -> 32^3, disp + vel", 32 ** 3, 4.317e12
+            else:
+                step = lambda: eng.process_box(x, (128,) * 3, (1, 1, 1), ((48, 48),) * 3, Dz, 0.0)
+                work, nvox, flop = "process_box 128^3 ndiv (1,1,1) compute_vel=False", 128 ** 3, None
+            for _ in range(3):
+                step()
+            fence()
+            eng.profile_reset(); eng.profile_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            fence()
+            dts = (time.perf_counter() - t0) / reps
+            eng.profile_enable(False)
+            pr = eng.profile_read()
+            rf = roofline(pr, args.precision) if pr else None
+            out[name] = {"workload": work, "value": nvox / dts, "unit": "voxels/s", "ms_per_step": 1e3 * dts, "steps": reps,
+                         "reference_accounting_tflops": (flop / dts / 1e12) if flop else None,
+                         "roofline": None if rf is None else {k: rf[k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches", "share_of_kernel_time")},
+                         "plan": (eng.query("slab"), eng.query("periodic_yx"), eng.query("periodic_z"))}
+            eng.close()
+        return out
+
+    small = measure_small_configs() if (world == 1 and not args.no_small_configs) else None
+
     if rank == 0:
         vox = float(N) ** 3
         dtype = {"f32": "f32", "f16x3": "f32-equivalent: f16x3 split MFMA (3 f16 MFMAs per product, f32 accumulate)",
@@ -334,6 +372,8 @@ def main():
             sdt, sprof, sok, _ = strict
             out["strict_f32"] = {"value": vox / sdt, "unit": "voxels/s", "ms_per_step": 1e3 * sdt, "steps": 1,
                                  "dtype": "f32", "finite": sok, "roofline": roofline(sprof, "f32") if sprof else None}
+        if small is not None:
+            out["baseline_configs_1_2"] = small
         if world == 1 and not args.no_cpu_baseline:
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             threads = min(avail, 16)        # the 1-GPU box's CPU share; more BLAS threads only oversubscribe

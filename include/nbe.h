@@ -168,17 +168,20 @@ int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3],
  * The ranks of a node cut the periodic box into slabs along z; a brick is periodic in y and x by itself.  What the network
  * needs from the z neighbours is EXCHANGED at the three places where it is smallest, instead of being recomputed from a
  * 48-plane halo of the raw input:
- *   which 0   8 planes of the raw input per side -- the level-0 encoder's reach beyond the brick ((C, 8, S1, S2) float32);
+ *   which 0   4 planes of the raw input per side -- the level-0 encoder's reach beyond the brick ((C, 4, S1, S2) float32);
  *   which 1   6 planes of the down_l0 output per side -- what conv_l1 reads beyond the brick for the level-1 skip connection;
- *   which 2   10 planes of the down_l1 output per side -- what levels 2 and 3 read.
- * nbe_brick_halo_bytes(ctx, brick_size, which) sizes one such face (device buffers, opaque 16-byte units for 1 and 2).
- *   nbe_brick_encode    haloed_brick = (C, b0 + 16, S1, S2): level-0 encoder; writes the first / last 6 down_l0 planes to
- *                       send_lo / send_hi;
+ *   which 2   10 planes of the down_l1 output per side -- what levels 2 and 3 read;
+ *   which 3   4 planes of the level-0 skip connection (conv_l01's output) per side -- what the decoder's first block reads
+ *             beyond the brick; needed last, it travels while levels 1-3 run.
+ * nbe_brick_halo_bytes(ctx, brick_size, which) sizes one such face (device buffers, opaque 16-byte units for 1 - 3).
+ *   nbe_brick_encode    haloed_brick = (C, b0 + 8, S1, S2): level-0 encoder on the brick's own planes; writes the first / last
+ *                       6 down_l0 planes to send_lo / send_hi and the first / last 4 skip-connection planes to skip_send_*;
  *   nbe_brick_interior  the part of conv_l1 that needs the brick's own planes only -- it runs while the faces travel;
  *   nbe_brick_exchange  with the neighbours' faces (recv_lo = the z-minus neighbour's send_hi, recv_hi = the z-plus
  *                       neighbour's send_lo): the rest of conv_l1, the skip connection, down_l1; writes the first / last
  *                       10 down_l1 planes to send2_lo / send2_hi;
- *   nbe_brick_finish    with the neighbours' second faces: levels 2-3, the decoders, the brick's (C, b0, S1, S2) fields.
+ *   nbe_brick_finish    with the neighbours' second faces and their skip-connection planes: levels 2-3, the decoders, the
+ *                       brick's (C, b0, S1, S2) fields.
  * The four calls must follow each other on one context (any other call in between invalidates the brick and the next
  * brick call fails); all are asynchronous on the context's stream -- the caller orders the exchanges against it (events).
  * EVERY RANK MUST USE THE SAME RANGE SHIFT: call nbe_set_input_range with the box-wide max |x| first (the shim all-reduces
@@ -189,11 +192,11 @@ int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3],
 int64_t nbe_brick_halo_bytes(nbe_ctx* ctx, const int64_t brick_size[3], int which);
 int nbe_brick_plan(nbe_ctx* ctx, const int64_t brick_size[3]);
 int nbe_brick_encode(nbe_ctx* ctx, const void* haloed_brick, const int64_t brick_size[3], float Dz, float vel_fac,
-                     void* send_lo, void* send_hi);
+                     void* send_lo, void* send_hi, void* skip_send_lo, void* skip_send_hi);
 int nbe_brick_interior(nbe_ctx* ctx);
 int nbe_brick_exchange(nbe_ctx* ctx, const void* recv_lo, const void* recv_hi, void* send2_lo, void* send2_hi);
-int nbe_brick_finish(nbe_ctx* ctx, const void* recv2_lo, const void* recv2_hi, float Dz, float vel_fac,
-                     void* disp, void* vel, int out_dtype);
+int nbe_brick_finish(nbe_ctx* ctx, const void* recv2_lo, const void* recv2_hi, const void* skip_recv_lo, const void* skip_recv_hi,
+                     float Dz, float vel_fac, void* disp, void* vel, int out_dtype);
 
 /* Internal tiling.  When crop_size = size/ndiv is a multiple of 8 on every axis, all crop origins keep the
  * phase of the network's 2^3 stride lattice, so the per-voxel result does not depend on how the box is cut

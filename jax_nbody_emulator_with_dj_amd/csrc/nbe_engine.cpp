@@ -167,7 +167,8 @@ struct nbe_ctx {
     // the neighbours' down_l0 outputs, exchanged between the two calls, instead of periodic wrap-around.
     bool zx = false;
     int phase = 0;                                // 0: whole schedule; 1: up to the exchange; 2: from the exchange on
-    struct BrickIO { void *send_lo = nullptr, *send_hi = nullptr; const void *recv_lo = nullptr, *recv_hi = nullptr; } bio;
+    struct BrickIO { void *send_lo = nullptr, *send_hi = nullptr; const void *recv_lo = nullptr, *recv_hi = nullptr;
+                     void *skip_send_lo = nullptr, *skip_send_hi = nullptr; const void *skip_recv_lo = nullptr, *skip_recv_hi = nullptr; } bio;
     struct StreamState {                          // what the next brick call resumes with (tensors in the arena, which is left alone in between)
         bool valid = false;
         int stage = 0;                            // the last phase that ran (1 encode, 2 interior, 3 edges)
@@ -973,7 +974,9 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
     // then produces the Y - 80 planes of the skip connection only, and down_l0 the box's own (D - 96) / 2 planes.
     const bool zx = pad && c->zx;                                 // brick mode: as pz, the z context of level 1 comes from the neighbours
     const bool pz = pad && (c->pz || zx);
-    const int zlo = pz ? 40 : 0, zhi = pz ? Y - 40 : Y;
+    // brick mode: the brick's own D - 96 planes of the skip connection only (planes 4 .. of the tensor) -- the four on either
+    // side that the decoder reads as well are the neighbours' own planes and arrive by exchange (network_stream)
+    const int zlo = pz ? (zx ? 44 : 40) : 0, zhi = pz ? (zx ? Y - 44 : Y - 40) : Y;
     // the level-0 skip connection: centre crop by 40 (z only in periodic-yx mode)
     Tensor skip0 = pad ? tallocp(c, m, Y - 80, Hi, Wi, pad) : talloc(c, m, Y - 80, H - 88, W - 88);
     // down_l0 output; periodic-yx: on the interior first (td), then extended by 22 voxels of periodic context (t)
@@ -1108,6 +1111,10 @@ static int stream_level1(nbe_ctx* c, int pad, bool pz, Tensor td, Tensor* cat1_o
 // planes for the level-1 skip connection: 4 + 2) and BRICK_H2 planes of the down_l1 output (what levels 2 and 3 read: 10).
 // Own planes of the level-1 input sit at [BRICK_H1, BRICK_H1 + B) of t.
 static constexpr int BRICK_H1 = 6, BRICK_H2 = 10;
+// ... and at the full-resolution level: BRICK_H0 planes of the skip connection (conv_l01's output) per side, which the decoder's
+// first block reads beyond the brick's own planes -- exchanged while levels 1-3 run, instead of 8 more planes through the four
+// layers of the level-0 encoder
+static constexpr int BRICK_H0 = 4;
 static Planes brick_planes(nbe_ctx* c, const Tensor& like, const void* buf, int nplanes) {
     Planes p = like.p;
     p.D = nplanes;
@@ -1296,6 +1303,10 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
             if (!c->dry) {
                 launch_crop(zview(st.td, 0, BRICK_H1).p, 0, brick_planes(c, st.td, c->bio.send_lo, BRICK_H1), 0, c->vel, c->stream, 0);
                 launch_crop(zview(st.td, st.td.p.D - BRICK_H1, BRICK_H1).p, 0, brick_planes(c, st.td, c->bio.send_hi, BRICK_H1), 0, c->vel, c->stream, 0);
+                // ... and the first / last four of the brick's own planes of the skip connection (planes 4 .. D - 4 of the tensor)
+                const int own = st.skip0.p.D - 2 * BRICK_H0;
+                launch_crop(zview(st.skip0, BRICK_H0, BRICK_H0).p, 0, brick_planes(c, st.skip0, c->bio.skip_send_lo, BRICK_H0), 0, c->vel, c->stream, 0);
+                launch_crop(zview(st.skip0, own, BRICK_H0).p, 0, brick_planes(c, st.skip0, c->bio.skip_send_hi, BRICK_H0), 0, c->vel, c->stream, 0);
             }
             st.valid = true; st.stage = 1; stash_arena(c);
             return 0;
@@ -1316,6 +1327,10 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     }
     Tensor t;
     if (brick_level2(c, st, &t)) return 1;
+    if (!c->dry && c->bio.skip_recv_lo) {                         // the neighbours' planes of the skip connection, below and above the own ones
+        launch_crop(brick_planes(c, st.skip0, c->bio.skip_recv_lo, BRICK_H0), 0, zview(st.skip0, 0, BRICK_H0).p, 0, c->vel, c->stream, 0);
+        launch_crop(brick_planes(c, st.skip0, c->bio.skip_recv_hi, BRICK_H0), 0, zview(st.skip0, st.skip0.p.D - BRICK_H0, BRICK_H0).p, 0, c->vel, c->stream, 0);
+    }
     st.valid = false;
     return stream_tail(c, st.tin, ho, st.S, st.skip0, st.cat1, t);
 }
@@ -2415,7 +2430,7 @@ int nbe_host_trim(void) {
 }
 
 // ---- brick mode: one rank's z-slab of a periodic box, the context below the full-resolution level exchanged ---------
-static constexpr int BRICK_RAW = 8;      // planes of RAW input a brick needs from either z neighbour (the level-0 encoder's reach)
+static constexpr int BRICK_RAW = 4;      // planes of RAW input a brick needs from either z neighbour (the level-0 encoder's reach for the brick's own planes)
 static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* W, int64_t* need_out = nullptr) {
     c->sst.valid = false;
     if (require_ready(c)) return 1;
@@ -2436,7 +2451,8 @@ static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* 
 }
 
 int64_t nbe_brick_halo_bytes(nbe_ctx* c, const int64_t bsize[3], int which) {
-    if (!c || !bsize || which < 0 || which > 2) return -1;
+    if (!c || !bsize || which < 0 || which > 3) return -1;
+    if (which == 3) return brick_halo_bytes(c, BRICK_H0, (int)bsize[1] + 2, (int)bsize[2] + 2);   // whole planes, wrap-around columns included
     if (which == 0) return (int64_t)c->in_chan * BRICK_RAW * bsize[1] * bsize[2] * 4;       // raw input planes, float32
     if (which == 1) return brick_halo_bytes(c, BRICK_H1, (int)bsize[1] / 2, (int)bsize[2] / 2);
     return brick_halo_bytes(c, BRICK_H2, (int)bsize[1] / 4, (int)bsize[2] / 4);
@@ -2456,9 +2472,11 @@ int nbe_brick_plan(nbe_ctx* c, const int64_t bsize[3]) {
 
 struct BrickOff { nbe_ctx* c; ~BrickOff() { c->phase = 0; c->zx = false; } };
 
-int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float Dz, float vel_fac, void* send_lo, void* send_hi) {
-    if (!c || !box || !send_lo || !send_hi) return fail("null argument");
-    if (!is_device_ptr(box) || !is_device_ptr(send_lo) || !is_device_ptr(send_hi)) return fail("nbe_brick_encode takes device pointers");
+int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float Dz, float vel_fac, void* send_lo, void* send_hi,
+                     void* skip_send_lo, void* skip_send_hi) {
+    if (!c || !box || !send_lo || !send_hi || !skip_send_lo || !skip_send_hi) return fail("null argument");
+    if (!is_device_ptr(box) || !is_device_ptr(send_lo) || !is_device_ptr(send_hi) || !is_device_ptr(skip_send_lo) || !is_device_ptr(skip_send_hi))
+        return fail("nbe_brick_encode takes device pointers");
     int D, H, W;
     if (brick_setup(c, bsize, &D, &H, &W)) return 1;
     BrickOff off{c};
@@ -2468,11 +2486,11 @@ int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float 
     c->arena.reset();
     Tensor tin = talloc(c, c->in_chan, D, H, W);
     tin.pad = 1; set_org(tin, 0, 48, 48);
-    // the haloed brick is (C, b0 + 16, S1, S2): planes [40, b0 + 56) of the tile's frame -- all the level-0 encoder reads (the
-    // head reads the brick's own planes); y and x periodic (origin -1)
+    // the haloed brick is (C, b0 + 8, S1, S2): planes [44, b0 + 52) of the tile's frame -- all the level-0 encoder reads for the
+    // brick's own planes of the skip connection (the head reads the brick's own input planes); y and x periodic (origin -1)
     launch_gather((const float*)box, c->in_chan, Dh, (int)bsize[1], (int)bsize[2], 0, -1, -1, zview(tin, 48 - BRICK_RAW, Dh).p,
                   Dz / 6.0f * c->act_scale, c->prec, c->stream);
-    c->phase = 1; c->bio.send_lo = send_lo; c->bio.send_hi = send_hi;
+    c->phase = 1; c->bio.send_lo = send_lo; c->bio.send_hi = send_hi; c->bio.skip_send_lo = skip_send_lo; c->bio.skip_send_hi = skip_send_hi;
     c->sst.D = D; c->sst.H = H; c->sst.W = W;
     c->sst.Dz = Dz; c->sst.vel_fac = vel_fac; c->sst.act_scale = c->act_scale; c->sst.ws = c->ws;
     const HeadOut ho{nullptr, nullptr, NBE_F32, (int)bsize[0], (int)bsize[1], (int)bsize[2], 0, 0, 0, Dz, vel_fac};
@@ -2510,15 +2528,16 @@ int nbe_brick_exchange(nbe_ctx* c, const void* recv_lo, const void* recv_hi, voi
     return 0;
 }
 
-int nbe_brick_finish(nbe_ctx* c, const void* recv_lo, const void* recv_hi, float Dz, float vel_fac, void* disp, void* vel, int out_dtype) {
-    if (!c || !recv_lo || !recv_hi || !disp) return fail("null argument");
+int nbe_brick_finish(nbe_ctx* c, const void* recv_lo, const void* recv_hi, const void* skip_recv_lo, const void* skip_recv_hi,
+                     float Dz, float vel_fac, void* disp, void* vel, int out_dtype) {
+    if (!c || !recv_lo || !recv_hi || !skip_recv_lo || !skip_recv_hi || !disp) return fail("null argument");
     if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
     if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
     if (brick_resume(c, 4)) return 1;
     BrickOff off{c};
     if (c->sst.Dz != Dz || c->sst.vel_fac != vel_fac || c->sst.act_scale != c->act_scale)
         return fail("nbe_brick_finish: Dz, vel_fac and the range shift must be those of the nbe_brick_encode call it completes");
-    c->bio.recv_lo = recv_lo; c->bio.recv_hi = recv_hi;
+    c->bio.recv_lo = recv_lo; c->bio.recv_hi = recv_hi; c->bio.skip_recv_lo = skip_recv_lo; c->bio.skip_recv_hi = skip_recv_hi;
     const int b0 = c->sst.D - 96, S1 = c->sst.H - 2, S2 = c->sst.W - 2;
     const HeadOut ho{disp, vel, out_dtype, b0, S1, S2, 0, 0, 0, Dz, vel_fac};
     if (network_stream(c, c->sst.tin, ho, c->sst.S)) return 1;

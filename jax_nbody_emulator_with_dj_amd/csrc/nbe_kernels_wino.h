@@ -171,35 +171,37 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         ld(g.ah, ra, 0); ld(g.al, ra, pso); ld(g.bh, rb, 0); ld(g.bl, rb, pso);
         g.sb = nx.sb;
     };
-    // V = (a hi + 2^-11 a lo) + sb (b hi + 2^-11 b lo) on two channels per register with the mixed-precision FMA (f16
-    // sources widened in the instruction: no conversions), then hi = f16(V), lo = f16((V - hi) 2^11): 11 VALU operations
-    // per channel pair (the compiler's own form of the same arithmetic: 17).  Sixteen micro-steps of two or three
-    // operations each: in the loop one follows every MFMA of two products, where it issues in the MFMA's shadow -- all
-    // waves of a workgroup reach the same point of a stage together, so a block of VALU work stalls the matrix pipe of
-    // its SIMD for its whole length (measured: 3.2 VALU per MFMA and 56 % matrix-busy with the transform in blocks).
-    struct Xf { u32x4 HI, LO; float t0, t1; unsigned h; };
+    // V = (a hi + 2^-11 a lo) + sb (b hi + 2^-11 b lo), two channels per register, entirely in packed f16 (round 3; before:
+    // joined to float32 with the mixed-precision FMA and split again, 11 operations per channel pair):
+    //     s   = a hi + sb b hi                          the new hi part (one rounding)
+    //     err = TwoSum's exact rounding error of s      (Knuth: bb = s - a hi; err = (a hi - (s - bb)) + (sb b hi - bb))
+    //     lo  = err 2^11 + (a lo + sb b lo)             the new lo part, scaled by 2^11 like every lo part
+    // 8 packed operations.  (s, lo) is not the canonical split of V -- s is the rounding of a hi + sb b hi, not of V -- but it
+    // represents V to the same absolute accuracy, 2^-23 (|a| + |b|): what the float32 form delivers too, since a and b carry
+    // 22 bits each; tools/wino_emulation.py reproduces both.  sb = +-1 is a packed constant of the stage (SGPR).
+    // Sixteen micro-steps of two operations each: in the loop one follows every MFMA of two products, where it issues in the
+    // MFMA's shadow -- all waves of a workgroup reach the same point of a stage together, so a block of VALU work stalls the
+    // matrix pipe of its SIMD for its whole length (measured: 3.2 VALU per MFMA and 56 % matrix-busy with the transform in blocks).
+    struct Xf { u32x4 HI, LO; unsigned s, bb, e1, e2, l1; };
     auto xf_step = [&](const Stg& g, Xf& x, int k) {
         const int r = k >> 2, m = k & 3;
         const unsigned AH = __builtin_bit_cast(u32x4, g.ah)[r], AL = __builtin_bit_cast(u32x4, g.al)[r];
         const unsigned BH = __builtin_bit_cast(u32x4, g.bh)[r], BL = __builtin_bit_cast(u32x4, g.bl)[r];
-        const float inv = H3_INV, sinv = g.sb * H3_INV, sb = g.sb, k2048 = H3_SCALE;
+        const unsigned sbp = g.sb < 0.f ? 0xBC00BC00u : 0x3C003C00u, k2048 = 0x68006800u;      // packed (sb, sb), (2048, 2048)
         if (m == 0) {
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x.t0) : "v"(AL), "s"(inv), "v"(AH));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(BL), "s"(sinv));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(BH), "s"(sb));
+            asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(x.s) : "v"(BH), "s"(sbp), "v"(AH));
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x.bb) : "v"(x.s), "v"(AH));
         } else if (m == 1) {
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x.t1) : "v"(AL), "s"(inv), "v"(AH));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(BL), "s"(sinv));
-            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(BH), "s"(sb));
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x.e1) : "v"(x.s), "v"(x.bb));          // s - bb
+            asm("v_pk_fma_f16 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(x.e2) : "v"(BH), "s"(sbp), "v"(x.bb));   // sb b hi - bb
         } else if (m == 2) {
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x.h) : "v"(x.t0), "v"(x.t1));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(x.h));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(x.h));
+            asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x.e1) : "v"(AH), "v"(x.e1));            // a hi - (s - bb)
+            asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(x.l1) : "v"(BL), "s"(sbp), "v"(AL));
         } else {
-            unsigned l;
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l) : "v"(x.t0), "s"(k2048));
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l) : "v"(x.t1), "s"(k2048));
-            x.HI[r] = x.h; x.LO[r] = l;
+            unsigned err, l;
+            asm("v_pk_add_f16 %0, %1, %2" : "=v"(err) : "v"(x.e1), "v"(x.e2));
+            asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(l) : "v"(err), "s"(k2048), "v"(x.l1));
+            x.HI[r] = x.s; x.LO[r] = l;
         }
     };
     auto st_write = [&](int j, int buf, const Xf& x) {

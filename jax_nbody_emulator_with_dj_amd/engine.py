@@ -291,10 +291,11 @@ class Engine:
                                          _ptr(disp), _ptr(vel), 1 if half else 0, i64(disp.shape[1:]), i64(out_origin)))
 
     # ---- brick mode (sharded box, z-slabs with one activation exchange per box) -------------------
-    RAW_HALO = 8            # planes of raw input a brick needs from either z neighbour (include/nbe.h, "Brick mode")
+    RAW_HALO = 4            # planes of raw input a brick needs from either z neighbour (include/nbe.h, "Brick mode")
 
     def brick_halo_bytes(self, bshape, which=1):
-        """Bytes of one exchanged face: which = 0 raw input (8 planes), 1 down_l0 output (6 planes), 2 down_l1 output (10)."""
+        """Bytes of one exchanged face: which = 0 raw input (4 planes), 1 down_l0 output (6 planes), 2 down_l1 output (10),
+        3 level-0 skip connection (4 planes)."""
         n = int(self._l.nbe_brick_halo_bytes(self._h, (C.c_int64 * 3)(*[int(v) for v in bshape]), int(which)))
         if n < 0:
             raise NBEError("nbe_brick_halo_bytes failed")
@@ -310,19 +311,21 @@ class Engine:
             if not t.is_cuda or t.numel() * t.element_size() < n:
                 raise NBEError("brick exchange buffers must be CUDA tensors of at least %d bytes" % n)
 
-    def brick_encode(self, haloed, bshape, Dz, vel_fac, send_lo, send_hi):
-        """haloed: CUDA tensor (C, b0 + 16, S1, S2); send_lo / send_hi: CUDA uint8 tensors of brick_halo_bytes(bshape, 1)."""
+    def brick_encode(self, haloed, bshape, Dz, vel_fac, send_lo, send_hi, skip_send_lo, skip_send_hi):
+        """haloed: CUDA tensor (C, b0 + 8, S1, S2); send_*: CUDA uint8 tensors of brick_halo_bytes(bshape, 1), skip_send_*: of
+        brick_halo_bytes(bshape, 3)."""
         self._follow_torch_stream(haloed)
         b = tuple(int(v) for v in bshape)
         self._brick = b
         # the kernels read exactly this much: check before anything is launched
         want = (self.in_chan, b[0] + 2 * self.RAW_HALO, b[1], b[2])
         if tuple(haloed.shape) != want or haloed.dtype != torch.float32 or not haloed.is_contiguous():
-            raise NBEError("haloed brick must be a contiguous float32 (C, b0 + 16, S1, S2) = %s tensor; got %s %s"
+            raise NBEError("haloed brick must be a contiguous float32 (C, b0 + 8, S1, S2) = %s tensor; got %s %s"
                            % (want, tuple(haloed.shape), haloed.dtype))
         self._check_faces(b, 1, send_lo, send_hi)
-        check(self._l.nbe_brick_encode(self._h, _ptr(haloed), (C.c_int64 * 3)(*b), float(Dz),
-                                       float(vel_fac), _ptr(send_lo), _ptr(send_hi)))
+        self._check_faces(b, 3, skip_send_lo, skip_send_hi)
+        check(self._l.nbe_brick_encode(self._h, _ptr(haloed), (C.c_int64 * 3)(*b), float(Dz), float(vel_fac),
+                                       _ptr(send_lo), _ptr(send_hi), _ptr(skip_send_lo), _ptr(skip_send_hi)))
 
     def brick_interior(self):
         check(self._l.nbe_brick_interior(self._h))
@@ -332,12 +335,13 @@ class Engine:
         self._check_faces(self._brick, 2, send2_lo, send2_hi)
         check(self._l.nbe_brick_exchange(self._h, _ptr(recv_lo), _ptr(recv_hi), _ptr(send2_lo), _ptr(send2_hi)))
 
-    def brick_finish(self, recv2_lo, recv2_hi, Dz, vel_fac, disp, vel):
+    def brick_finish(self, recv2_lo, recv2_hi, skip_recv_lo, skip_recv_hi, Dz, vel_fac, disp, vel):
         self._follow_torch_stream(disp)
         half = disp.element_size() == 2
         self._check_faces(self._brick, 2, recv2_lo, recv2_hi)
-        check(self._l.nbe_brick_finish(self._h, _ptr(recv2_lo), _ptr(recv2_hi), float(Dz), float(vel_fac), _ptr(disp),
-                                       _ptr(vel), 1 if half else 0))
+        self._check_faces(self._brick, 3, skip_recv_lo, skip_recv_hi)
+        check(self._l.nbe_brick_finish(self._h, _ptr(recv2_lo), _ptr(recv2_hi), _ptr(skip_recv_lo), _ptr(skip_recv_hi),
+                                       float(Dz), float(vel_fac), _ptr(disp), _ptr(vel), 1 if half else 0))
 
     # ---- test hooks ---------------------------------------------------------------------------
     def test_layer(self, kind, x, w, bias, dx=None, dw=None, crop=0, act=False, res=None, dres=None):

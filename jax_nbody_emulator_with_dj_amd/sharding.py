@@ -16,12 +16,12 @@ z-slab bricks (rank grid (N,1,1), the default whenever a slab is at least 48 pla
 A brick that is not split in y and x is periodic there by itself, so only its z halo costs
 anything -- and almost all of that cost sits BELOW the full-resolution level: the 48-plane halo of
 the raw input exists to give levels 1-3 their context.  Instead of recomputing it, the ranks
-exchange what each level needs where it is smallest (include/nbe.h, "Brick mode"): 8 planes of raw
-input per side (25 MB at 512^2), 6 planes of the down_l0 output (201 MB; the interior of conv_l1
-runs while they travel, on the communication stream), 10 planes of the down_l1 output (84 MB).
-What is still recomputed is the level-0 halo of 4 + 4 planes, 4 + 4 planes of conv_l1 and the
-10-plane halo of levels 2-3 (1.5 % of the work): 1.14 x the ideal at 8 ranks (1.25 x with one
-exchange of 22 planes, round 2; 1.45 x with padded 256^3 bricks).  The fields equal the single-GPU run
+exchange what each level needs where it is smallest (include/nbe.h, "Brick mode"): 4 planes of raw
+input per side (13 MB at 512^2), 6 planes of the down_l0 output (201 MB; the interior of conv_l1
+runs while they travel, on the communication stream), 10 planes of the down_l1 output (84 MB), and
+4 planes of the level-0 skip connection (541 MB, needed by the decoder only: they travel while
+levels 1-3 run).  What is still recomputed is 2 planes per layer and side inside the level-0 blocks,
+4 + 4 planes of conv_l1 and the 10-plane halo of levels 2-3 (1.5 % of the work).  The fields equal the single-GPU run
 (bit for bit on the direct kernels; to float32 rounding where the Winograd-z kernel pairs planes
 differently).  The exchange buffers are allocated once per ShardedBox.  A brick whose workspace does
 not fit the memory that is free (all ranks agree on that with a 4-byte all-reduce) falls back to the
@@ -41,14 +41,14 @@ PAD = 48
 
 
 BRICK_MIN_DEPTH = 48          # a brick hands 10 planes of its down_l1 output (a quarter of its depth) to either neighbour
-RAW_HALO = 8                  # planes of raw input a brick needs from either z neighbour
+RAW_HALO = 4                  # planes of raw input a brick needs from either z neighbour
 
 
 def _zbrick_factor(e0):
     """Work per output voxel of a z-slab brick of depth e0 with the three exchanges, relative to no halo at all:
-    level 0 (90 % of the FLOPs) computes ~7 extra planes, level 1 (8.5 %) ~7 extra half-resolution planes, levels 2-3
+    level 0 (90 % of the FLOPs) computes ~4 extra planes, level 1 (8.5 %) ~7 extra half-resolution planes, levels 2-3
     (1.5 %) 20 quarter-resolution ones."""
-    return 1.0 + 0.90 * 7.0 / e0 + 0.085 * 7.0 / (e0 / 2.0) + 0.015 * 20.0 / (e0 / 4.0)
+    return 1.0 + 0.90 * 4.0 / e0 + 0.085 * 7.0 / (e0 / 2.0) + 0.015 * 20.0 / (e0 / 4.0)
 
 
 def _halo_factor(e):
@@ -255,21 +255,23 @@ class ShardedBox:
         never waits for a transfer it could not have overlapped: the 6-plane faces of the down_l0 output travel under the
         interior of conv_l1."""
         cur = torch.cuda.current_stream(brick.device)
-        H = exchange_halo(brick, self.grid, self.coords, RAW_HALO, self.group, pad_unsplit=False)     # raw input, 8 planes in z
+        H = exchange_halo(brick, self.grid, self.coords, RAW_HALO, self.group, pad_unsplit=False)     # raw input, 4 planes in z
         if self._halo is None or self._halo[0].device != brick.device:
-            n1, n2 = self.eng.brick_halo_bytes(self.bshape, 1), self.eng.brick_halo_bytes(self.bshape, 2)
-            self._halo = tuple(torch.empty(n, dtype=torch.uint8, device=brick.device) for n in (n1,) * 4 + (n2,) * 4)
-        s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi = self._halo
-        self.eng.brick_encode(H, self.bshape, Dz, vel_fac, s_lo, s_hi)
+            n = [self.eng.brick_halo_bytes(self.bshape, w) for w in (1, 2, 3)]
+            self._halo = tuple(torch.empty(k, dtype=torch.uint8, device=brick.device) for k in (n[0],) * 4 + (n[1],) * 4 + (n[2],) * 4)
+        s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi, k_lo, k_hi, q_lo, q_hi = self._halo
+        self.eng.brick_encode(H, self.bshape, Dz, vel_fac, s_lo, s_hi, k_lo, k_hi)
         ev = self._exchange_async(cur, s_lo, s_hi, r_lo, r_hi)
+        ev_skip = self._exchange_async(cur, k_lo, k_hi, q_lo, q_hi)   # the skip connection's planes: needed by the decoder only
         self.eng.brick_interior()                                   # runs while the faces travel
         if ev is not None:
             cur.wait_event(ev)
         self.eng.brick_exchange(r_lo, r_hi, s2_lo, s2_hi)
         ev = self._exchange_async(cur, s2_lo, s2_hi, r2_lo, r2_hi)
-        if ev is not None:
-            cur.wait_event(ev)
-        self.eng.brick_finish(r2_lo, r2_hi, Dz, vel_fac, disp, vel)
+        for e in (ev, ev_skip):
+            if e is not None:
+                cur.wait_event(e)
+        self.eng.brick_finish(r2_lo, r2_hi, q_lo, q_hi, Dz, vel_fac, disp, vel)
 
     def _agree_on_bricks(self, device):
         """A brick whose workspace does not fit the memory that is free now runs as padded bricks instead; every rank must

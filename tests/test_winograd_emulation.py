@@ -45,3 +45,23 @@ def test_winograd_z_emulation_follows_the_direct_form_over_the_f16_range():
         ye = W.conv_exact(xs, w)
         e_w, e_d = W.rel(W.conv_winograd_z(xs, w), ye), W.rel(W.conv_f16x3_direct(xs, w), ye)
         assert e_w <= 2e-6 and e_w <= 4 * e_d + 1e-7, (s, e_w, e_d)
+
+
+def test_packed_f16_transform_matches_the_float32_one():
+    """xf_step's transform (round 3): s = a hi +- b hi in f16, TwoSum's exact error and the lo parts into the new lo part.
+    It represents V = a +- b to within 2^-21 (|a| + |b|) -- the float32 transform it replaces: 2^-23; both below the 2^-22 the
+    operands themselves carry per part -- also where a and b cancel; the layer's error moves from 3.4e-7 to 3.5e-7."""
+    x, w = _case(32, 16, (6, 7, 9), 4)
+    ye = W.conv_exact(x, w)
+    e16, e32 = W.rel(W.conv_winograd_z(x, w), ye), W.rel(W.conv_winograd_z(x, w, transform='f32'), ye)
+    assert e16 <= 2e-6 and e16 <= 1.5 * e32 + 1e-7, (e16, e32)
+    rng = np.random.default_rng(5)
+    a = W.f32(rng.standard_normal(20000))
+    b = W.f32(a * (1 + 1e-3 * rng.standard_normal(20000)))      # nearly equal: a - b cancels
+    ah, al = W.split_scaled(a)
+    bh, bl = W.split_scaled(b)
+    for sb in (-1.0, 1.0):
+        s, lo = W.transform_f16(ah, al, bh, bl, sb)
+        exact = (ah + al / 2048.0) + sb * (bh + bl / 2048.0)
+        err = np.abs(s + lo / 2048.0 - exact) / (np.abs(a) + np.abs(b))
+        assert err.max() <= 2.0 ** -21, (sb, err.max())

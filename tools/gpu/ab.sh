@@ -6,7 +6,7 @@
 # i.e. on one device: the pool's devices differ by ~5 % on this workload, so only such pairs are comparable.
 set -o pipefail
 TAG=${1:?tag}; VAR=${2:?variable}; OFF=${3:?off value}; ON=${4:?on value}; KEXPR=${5:-}; shift 5 2>/dev/null || shift $#
-B="--no-strict --no-host-path --no-cpu-baseline $*"
+B="--no-strict --no-host-path --no-cpu-baseline --no-small-configs $*"
 mkdir -p gpurun_out
 if [ -n "$KEXPR" ]; then
     timeout -k 10 400 python -m pytest tests/test_gpu_layers.py tests/test_gpu_model.py -x -q -m gpu -k "$KEXPR" > gpurun_out/${TAG}_tests.log 2>&1 || { tail -20 gpurun_out/${TAG}_tests.log; exit 1; }

@@ -17,7 +17,7 @@ done
 R=$(pwd)
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-strict --no-host-path $EXTRA"
+B="python3 $R/bench.py --no-cpu-baseline --no-strict --no-host-path --no-small-configs $EXTRA"
 cd /tmp
 for p in $PASSES; do
   case $p in

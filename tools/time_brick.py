@@ -1,8 +1,8 @@
 """One rank's share of an N-GPU run of the 512^3 box, timed on one card.
 
   z-slab bricks (rank grid (N,1,1), sharding.py): periodic in y and x; per box three exchanges with either z neighbour --
-  8 planes of raw input, 6 planes of the down_l0 output (the interior of conv_l1 runs meanwhile), 10 planes of the down_l1
-  output -- here copied from the brick's own send buffers on a second stream (same bytes, same kernels, same stream
+  4 planes of raw input, 6 planes of the down_l0 output (the interior of conv_l1 runs meanwhile), 10 planes of the down_l1
+  output, 4 planes of the level-0 skip connection (under levels 1-3) -- here copied from the brick's own send buffers on a second stream (same bytes, same kernels, same stream
   choreography as sharding.ShardedBox._process_zbrick, no link) -- Engine.brick_encode / brick_interior / brick_exchange /
   brick_finish.
   padded bricks (the round-1 scheme, NBE_ZBRICKS=0): haloed along the axes the rank grid splits, halo recomputed."""
@@ -29,11 +29,13 @@ for n in (1, 2, 4, 8):
         print("N=1 whole box, one periodic tile: %.3f s -> %.1f Mvox/s" % (dt, N ** 3 / dt / 1e6), flush=True)
         del box, d, v
         continue
-    H = torch.randn((3, b[0] + 16, N, N), device="cuda")
+    H = torch.randn((3, b[0] + 8, N, N), device="cuda")
     disp = torch.zeros((3,) + b, device="cuda"); vel = torch.zeros_like(disp)
     n1, n2 = e.brick_halo_bytes(b, 1), e.brick_halo_bytes(b, 2)
     s_lo, s_hi, r_lo, r_hi = (torch.empty(n1, dtype=torch.uint8, device="cuda") for _ in range(4))
     s2_lo, s2_hi, r2_lo, r2_hi = (torch.empty(n2, dtype=torch.uint8, device="cuda") for _ in range(4))
+    n3 = e.brick_halo_bytes(b, 3)
+    k_lo, k_hi, q_lo, q_hi = (torch.empty(n3, dtype=torch.uint8, device="cuda") for _ in range(4))
     cur, comm = torch.cuda.current_stream(), torch.cuda.Stream()
 
     def exchange(a_lo, a_hi, b_lo, b_hi):
@@ -45,17 +47,19 @@ for n in (1, 2, 4, 8):
 
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        e.brick_encode(H, b, 0.77, 50.0, s_lo, s_hi)
+        e.brick_encode(H, b, 0.77, 50.0, s_lo, s_hi, k_lo, k_hi)
         ev = exchange(s_lo, s_hi, r_lo, r_hi)
+        ev_skip = exchange(k_lo, k_hi, q_lo, q_hi)
         e.brick_interior()
         cur.wait_event(ev)
         e.brick_exchange(r_lo, r_hi, s2_lo, s2_hi)
         cur.wait_event(exchange(s2_lo, s2_hi, r2_lo, r2_hi))
-        e.brick_finish(r2_lo, r2_hi, 0.77, 50.0, disp, vel)
+        cur.wait_event(ev_skip)
+        e.brick_finish(r2_lo, r2_hi, q_lo, q_hi, 0.77, 50.0, disp, vel)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("N=%d z-slab brick %s, exchanges of %.0f + %.0f + %.0f MB per direction: %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
-          % (n, b, e.brick_halo_bytes(b, 0) / 1e6, n1 / 1e6, n2 / 1e6, dt, N ** 3 / dt / 1e6, t1 / (n * dt)), flush=True)
-    del H, disp, vel, s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi
+    print("N=%d z-slab brick %s, exchanges of %.0f + %.0f + %.0f + %.0f MB per direction: %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
+          % (n, b, e.brick_halo_bytes(b, 0) / 1e6, n1 / 1e6, n2 / 1e6, n3 / 1e6, dt, N ** 3 / dt / 1e6, t1 / (n * dt)), flush=True)
+    del H, disp, vel, s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi, k_lo, k_hi, q_lo, q_hi
     torch.cuda.empty_cache()
 # the padded scheme of round 1 for comparison
 for name, grid in (("N=8 (2,2,2)", (2, 2, 2)), ("N=4 (4,1,1)", (4, 1, 1))):

@@ -1,8 +1,9 @@
 """NumPy emulation of conv_h3w_kernel's arithmetic (csrc/nbe_kernels_wino.h) against an exact float64 convolution:
 Winograd F(2,3) along z with the two-phase K order (xi = 1 -> A, xi = 2 -> B; butterfly; xi = 0 -> A, xi = 3 -> B with U3
 negated), weights scaled by 2^14 and split into f16 hi + UNSCALED f16 lo, hi * 2^-11 as the weight operand of the lo(x)
-product, activations joined / transformed / re-split in float32, one float32 accumulator per output rounded after every
-16-channel tap product.  Beside it the direct f16x3 form of conv_h3g_kernel (separate main / correction accumulators).
+product, activations transformed in packed f16 on their (hi, lo) parts (round 3: s = a hi +- b hi, TwoSum's exact rounding
+error of s into the lo part; `transform='f32'` is the round-2 form: joined, transformed and re-split in float32), one
+float32 accumulator per output rounded after every 16-channel tap product.  Beside it the direct f16x3 form of conv_h3g_kernel (separate main / correction accumulators).
 
   python tools/wino_emulation.py            # 64 -> 64 channels, prints relative L2 errors at a few input scales
 """
@@ -48,7 +49,16 @@ def conv_f16x3_direct(x, w):
     return f32(ym + yc / 2048.0)
 
 
-def conv_winograd_z(x, w, S=2.0 ** 14):
+def transform_f16(ah, al, bh, bl, sb):
+    """V = a + sb b on (hi, lo * 2^11) parts in f16 arithmetic, as xf_step does it: returns (s, lo)."""
+    s = f16(ah + sb * bh)
+    bb = f16(s - ah)
+    err = f16(f16(ah - f16(s - bb)) + f16(sb * bh - bb))          # exact (TwoSum)
+    lo = f16(err * 2048.0 + f16(al + sb * bl))                    # fma: one rounding
+    return s, lo
+
+
+def conv_winograd_z(x, w, S=2.0 ** 14, transform='f16'):
     cout, cin = w.shape[:2]
     D, H, W = x.shape[1:]
     Do, Ho, Wo = D - 2, H - 2, W - 2
@@ -58,14 +68,19 @@ def conv_winograd_z(x, w, S=2.0 ** 14):
     Uh = f16(U)
     Ul = f16(U - Uh)                                              # unscaled remainder
     Uhp = f16(Uh / 2048.0)                                        # v_pk_mul_f16 by 2^-11
-    xj = f32(f16(x) + split_scaled(x)[1] / 2048.0)                # the stored (hi, lo) planes, joined in float32
+    xh, xl = split_scaled(x)                                      # the stored (hi, lo) planes
+    xj = f32(xh + xl / 2048.0)                                    # ... joined in float32 (round-2 form)
+    PA, PB, SB = (0, 1, 2, 1), (2, 2, 1, 3), (-1.0, 1.0, -1.0, -1.0)   # launch_h3w: V_xi = d[PA] + SB d[PB]
     y = np.zeros((cout, Do, Ho, Wo))
     for p in range(Do // 2):
         d = [xj[:, 2 * p + k] for k in range(4)]
         V = [f32(d[0] - d[2]), f32(d[1] + d[2]), f32(d[2] - d[1]), f32(d[1] - d[3])]
 
         def run(acc, xi):
-            Vh, Vl = split_scaled(V[xi])
+            if transform == 'f16':
+                Vh, Vl = transform_f16(xh[:, 2 * p + PA[xi]], xl[:, 2 * p + PA[xi]], xh[:, 2 * p + PB[xi]], xl[:, 2 * p + PB[xi]], SB[xi])
+            else:
+                Vh, Vl = split_scaled(V[xi])
             for c0 in range(0, cin, 16):
                 for dy in range(3):
                     for dx in range(3):
@@ -97,7 +112,8 @@ if __name__ == "__main__":
     w = f32(unit_rows(rng.standard_normal((cout, cin, 3, 3, 3))))
     ye = conv_exact(x, w)
     print("direct f16x3      rel-L2 %.2e" % rel(conv_f16x3_direct(x, w), ye))
-    print("Winograd-z merged rel-L2 %.2e" % rel(conv_winograd_z(x, w), ye))
+    print("Winograd-z merged rel-L2 %.2e (packed-f16 TwoSum transform), %.2e (float32 transform, round 2)"
+          % (rel(conv_winograd_z(x, w), ye), rel(conv_winograd_z(x, w, transform='f32'), ye)))
     for s in (1e-3, 30.0, 1e3):
         xs = f32(x * s)
         print("  input scale %g: %.2e" % (s, rel(conv_winograd_z(xs, w), conv_exact(xs, w))))
