@@ -2144,11 +2144,21 @@ __global__ __launch_bounds__(256) void pack_stem_kernel(const float* __restrict_
     dst[idx] = part == 0 ? hi : (_Float16)((v - (float)hi) * H3_SCALE);
 }
 
+// Which kernel runs a layer.  Generations that no default or fall-back reaches any more -- the flat tiling of the 3x3x3
+// layers, its 3-deep ring, the de-bursted DMA issue, the flat first layer, the 4 x 4 wave tile with one wave per SIMD
+// (DESIGN.md sections 4 and 4c have their measurements) -- are instantiated in timing-probe builds (-DNBE_DBG=1) only, behind
+// their old switches (NBE_H3_FLAT, NBE_H3_DEPTH, NBE_H3_SCHED, NBE_L0_FLAT, NBE_H3G_BIG).
 int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx, hipStream_t s) {
     const int ct = pw.ctiles;
+#if NBE_DBG
     static const int depth = (getenv("NBE_H3_DEPTH") && atoi(getenv("NBE_H3_DEPTH")) == 3) ? 3 : 2;
     static const bool flat3 = getenv("NBE_H3_FLAT") && atoi(getenv("NBE_H3_FLAT")) != 0;   // A/B: flat 3x3x3 tiling
     static const int sched = (getenv("NBE_H3_SCHED") && atoi(getenv("NBE_H3_SCHED")) == 1) ? 1 : 0;
+    static const bool l0_flat = getenv("NBE_L0_FLAT") && atoi(getenv("NBE_L0_FLAT")) == 1;
+#else
+    constexpr int depth = 2, sched = 0;
+    constexpr bool flat3 = false, l0_flat = false;
+#endif
     const bool split = pw.prec == PREC_F16X3;
     const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);   // A/B switch, default on (read per launch: tests flip it)
     if (stem_on && ka.stem_w && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
@@ -2169,34 +2179,36 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         if (split) {
             const bool tall = !(getenv("NBE_H3G_TALL") && atoi(getenv("NBE_H3G_TALL")) == 0);   // A/B switch, default on (read per launch)
             if (pw.cout_t == 16) return launch_h3g<true, false>(ka, ct, s);
-            const bool big = getenv("NBE_H3G_BIG") && atoi(getenv("NBE_H3G_BIG")) == 1;   // A/B switch: 4 x 4 wave tile, one wave per SIMD
-            if (big) return launch_h3g<false, false, true>(ka, ct, s);
+#if NBE_DBG
+            if (getenv("NBE_H3G_BIG") && atoi(getenv("NBE_H3G_BIG")) == 1) return launch_h3g<false, false, true>(ka, ct, s);   // 4 x 4 wave tile, one wave per SIMD
+#endif
             if (ka.ww && launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s) == 0) return 0;     // Winograd along z; 1: no such form for this launch
             return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
         }
         return launch_h2q<false, true>(ka, ct, s);
     }
-    // A/B switch (NBE_L0_FLAT=1): the first layer (no input tangent, Cin = 3 padded to 16; 64 channels x (hi, lo) x (y, dy)
-    // out for 3 channels in) on the flat tiling, which stores 4 KB runs per plane where the 8 x 32 patch tiling stores
-    // 512-byte row pieces.  Measured: 49.1 vs 47.6 ms per box -- the layer is not limited by the shape of its stores
-    // (nor by their width: 16-byte stores through v_permlane32_swap changed nothing either); its matrix pipe is 43 % busy
-    // on a K padded from 81 to 432.
-    static const bool l0_flat = getenv("NBE_L0_FLAT") && atoi(getenv("NBE_L0_FLAT")) == 1;
     const bool first_flat = l0_flat && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.nchunk == 1;
-    if (pw.mode == MODE_FLAT3 && !flat3 && !first_flat && ka.in_off == 0 && ka.osz == 1) {
+    if (pw.mode == MODE_FLAT3 && !flat3 && !first_flat) {
+        if (!(ka.in_off == 0 && ka.osz == 1)) return 1;          // 3x3x3 layers are never cropped or strided
         if (split && vel && has_dx && !shape32 && sched == 0) return launch_h3q(ka, ct, s);
         if (split && !vel && ka.ww && launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s, true) == 0) return 0;   // Winograd along z, displacement only
         if (split && !vel && !shape32) return launch_h2q<true>(ka, ct, s);
         if (!split && vel && has_dx && !shape32) return launch_h2q<false>(ka, ct, s);
         if (!split) { NBE_VD(launch_h3p_v, 0, false) }
+#if NBE_DBG
         else if (sched == 1) { NBE_VD(launch_h3p_v, 1, true) }
+#endif
         else { NBE_VD(launch_h3p_v, 0, true) }
         return 0;
     }
     if (pw.mode == MODE_FLAT3) {
+#if NBE_DBG
         if (!split) { NBE_VD(launch_h3_v, MODE_FLAT3, 2, false) }
         else if (depth == 3) { NBE_VD(launch_h3_v, MODE_FLAT3, 3, true) }
         else { NBE_VD(launch_h3_v, MODE_FLAT3, 2, true) }
+#else
+        return 1;
+#endif
     } else if (pw.mode == MODE_FLAT1) {
         if (ka.up8) return (split && vel && has_dx) ? launch_up_h3(ka, ct, s) : 1;      // all eight parities in one launch
         if (!split) { NBE_VD(launch_h3_v, MODE_FLAT1, 2, false) } else { NBE_VD(launch_h3_v, MODE_FLAT1, 2, true) }
@@ -2204,6 +2216,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         if (!split) { NBE_VD(launch_h3_v, MODE_DOWN, 2, false) } else { NBE_VD(launch_h3_v, MODE_DOWN, 2, true) }
     }
 #undef NBE_VD
+    (void)depth;
     return 0;
 }
 

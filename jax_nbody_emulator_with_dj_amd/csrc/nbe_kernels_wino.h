@@ -182,6 +182,33 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // Sixteen micro-steps of two operations each: in the loop one follows every MFMA of two products, where it issues in the
     // MFMA's shadow -- all waves of a workgroup reach the same point of a stage together, so a block of VALU work stalls the
     // matrix pipe of its SIMD for its whole length (measured: 3.2 VALU per MFMA and 56 % matrix-busy with the transform in blocks).
+#if NBE_XF_F32   // A/B build: the round-2 transform (joined to float32 with the mixed-precision FMA, 11 operations per channel pair)
+    struct Xf { u32x4 HI, LO; float t0, t1; unsigned h; };
+    auto xf_step = [&](const Stg& g, Xf& x, int k) {
+        const int r = k >> 2, m = k & 3;
+        const unsigned AH = __builtin_bit_cast(u32x4, g.ah)[r], AL = __builtin_bit_cast(u32x4, g.al)[r];
+        const unsigned BH = __builtin_bit_cast(u32x4, g.bh)[r], BL = __builtin_bit_cast(u32x4, g.bl)[r];
+        const float inv = H3_INV, sinv = g.sb * H3_INV, sb = g.sb, k2048 = H3_SCALE;
+        if (m == 0) {
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x.t0) : "v"(AL), "s"(inv), "v"(AH));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(BL), "s"(sinv));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(BH), "s"(sb));
+        } else if (m == 1) {
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x.t1) : "v"(AL), "s"(inv), "v"(AH));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(BL), "s"(sinv));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(BH), "s"(sb));
+        } else if (m == 2) {
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x.h) : "v"(x.t0), "v"(x.t1));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t0) : "v"(x.h));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x.t1) : "v"(x.h));
+        } else {
+            unsigned l;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l) : "v"(x.t0), "s"(k2048));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l) : "v"(x.t1), "s"(k2048));
+            x.HI[r] = x.h; x.LO[r] = l;
+        }
+    };
+#else
     struct Xf { u32x4 HI, LO; unsigned s, bb, e1, e2, l1; };
     auto xf_step = [&](const Stg& g, Xf& x, int k) {
         const int r = k >> 2, m = k & 3;
@@ -204,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             x.HI[r] = x.s; x.LO[r] = l;
         }
     };
+#endif
     auto st_write = [&](int j, int buf, const Xf& x) {
         bool valid;
         const int n = wave + NW * j;

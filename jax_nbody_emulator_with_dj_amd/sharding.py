@@ -238,7 +238,7 @@ class ShardedBox:
         """Face exchange on the communication stream, behind what `cur` has enqueued so far; returns the event the consumer
         waits for (None: the exchange ran on `cur` itself)."""
         comm = self.comm_stream
-        if comm is None or comm == cur:
+        if cur is None or comm is None or comm == cur:          # (CPU tensors: the gloo tests of the protocol)
             exchange_z_faces(send_lo, send_hi, recv_lo, recv_hi, self.coords, self.grid, self.group)
             return None
         comm.wait_stream(cur)
@@ -254,7 +254,7 @@ class ShardedBox:
         """z-slab brick: three small exchanges instead of a recomputed 48-plane halo (module docstring).  The compute stream
         never waits for a transfer it could not have overlapped: the 6-plane faces of the down_l0 output travel under the
         interior of conv_l1."""
-        cur = torch.cuda.current_stream(brick.device)
+        cur = torch.cuda.current_stream(brick.device) if brick.is_cuda else None
         H = exchange_halo(brick, self.grid, self.coords, RAW_HALO, self.group, pad_unsplit=False)     # raw input, 4 planes in z
         if self._halo is None or self._halo[0].device != brick.device:
             n = [self.eng.brick_halo_bytes(self.bshape, w) for w in (1, 2, 3)]
@@ -345,7 +345,7 @@ class ShardedBox:
             self.eng = keep
 
     def _process_on(self, brick, Dz, vel_fac, disp, vel):
-        cur = torch.cuda.current_stream(brick.device)
+        cur = torch.cuda.current_stream(brick.device) if brick.is_cuda else None
         self._agree_on_bricks(brick.device)
         # one range shift for the whole box (include/nbe.h, "Range"): max |x| over all bricks, a 4-byte all-reduce --
         # every rank then computes its brick with the arithmetic a single-GPU run of the box would use

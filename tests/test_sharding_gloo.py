@@ -150,3 +150,107 @@ def test_z_face_exchange(world):
     ra, rb = torch.zeros(5, dtype=torch.uint8), torch.zeros(5, dtype=torch.uint8)
     S.exchange_z_faces(a, b, ra, rb, (0, 0, 0), (1, 1, 1))
     assert torch.equal(ra, b) and torch.equal(rb, a)
+
+
+class _FakeEngine:
+    """Stands in for Engine in the CPU test of ShardedBox's brick protocol: records the calls, marks the faces it hands
+    out with its rank, checks the faces it receives, and can pretend that an activation left the f16 range."""
+    RAW_HALO = 4
+
+    def __init__(self, rank, world, bad=False):
+        self.rank, self.world, self.bad, self.calls, self.range = rank, world, bad, [], "unset"
+
+    def set_input_range(self, a):
+        self.range = a
+
+    def brick_plan(self, b):
+        return 32
+
+    def brick_halo_bytes(self, b, which):
+        return {1: 64, 2: 32, 3: 48}[which]
+
+    def brick_encode(self, H, b, Dz, vf, s_lo, s_hi, k_lo, k_hi):
+        assert tuple(H.shape) == (3, b[0] + 8, b[1], b[2]) and self.range is not None and self.range != "unset"
+        for t, v in ((s_lo, 1), (s_hi, 2), (k_lo, 5), (k_hi, 6)):
+            t.fill_(10 * self.rank + v)
+        self.calls.append("encode")
+
+    def brick_interior(self):
+        self.calls.append("interior")
+
+    def brick_exchange(self, r_lo, r_hi, s2_lo, s2_hi):
+        minus, plus = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        assert bool((r_lo == 10 * minus + 2).all()) and bool((r_hi == 10 * plus + 1).all())
+        s2_lo.fill_(10 * self.rank + 3); s2_hi.fill_(10 * self.rank + 4)
+        self.calls.append("exchange")
+
+    def brick_finish(self, r2_lo, r2_hi, q_lo, q_hi, Dz, vf, disp, vel):
+        minus, plus = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        assert bool((r2_lo == 10 * minus + 4).all()) and bool((r2_hi == 10 * plus + 3).all())
+        assert bool((q_lo == 10 * minus + 6).all()) and bool((q_hi == 10 * plus + 5).all())
+        disp.fill_(float(self.rank)); vel.fill_(float(self.rank))
+        self.calls.append("finish")
+
+    def check_finite(self):
+        from jax_nbody_emulator_with_dj_amd.engine import NBERangeError
+        if self.bad:
+            raise NBERangeError("non-finite values in the output of a finite input (fake)")
+
+
+def _protocol_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from jax_nbody_emulator_with_dj_amd.engine import NBERangeError
+        size, ndiv = (48 * world, 48, 48), (world, 1, 1)
+        brick = torch.full((3, 48, 48, 48), float(rank + 1))
+        disp, vel = torch.zeros_like(brick), torch.zeros_like(brick)
+        out = {}
+        # 1. a clean step: the four brick calls in order, one range for all ranks, cleared afterwards
+        e = _FakeEngine(rank, world)
+        sb = S.ShardedBox(e, size, ndiv, rank, world)
+        assert sb.zbricks and sb.grid == (world, 1, 1)
+        sb.process(brick, 0.77, 50.0, disp, vel)
+        out["clean"] = e.calls == ["encode", "interior", "exchange", "finish"] and e.range is None and float(disp[0, 0, 0, 0]) == rank
+        # 2. rank 1 overflows: EVERY rank raises, none is left in a collective, and the preset range is cleared
+        e = _FakeEngine(rank, world, bad=(rank == 1))
+        sb = S.ShardedBox(e, size, ndiv, rank, world)
+        try:
+            sb.process(brick, 0.77, 50.0, disp, vel)
+            out["raise"] = False
+        except NBERangeError:
+            out["raise"] = e.range is None
+        # 3. with strict-float32 engines as fallback every rank recomputes, together
+        e = _FakeEngine(rank, world, bad=(rank == 1))
+        fb = _FakeEngine(rank, world)
+        sb = S.ShardedBox(e, size, ndiv, rank, world)
+        sb.fallback = fb
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sb.process(brick, 0.77, 50.0, disp, vel)
+        out["fallback"] = fb.calls == ["encode", "interior", "exchange", "finish"] and fb.range is None and e.range is None
+        dist.barrier()                                             # nobody is stuck
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_brick_protocol_and_collective_error_handling(world):
+    """ShardedBox with z-slab bricks on CPU tensors and a fake engine: the call order and the routing of all four exchanges
+    (also world 2, where both neighbours are one rank), the box-wide range preset being cleared after every step, and the
+    ranks agreeing on a range error: all raise, or all recompute on their fallback engines -- nobody hangs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_protocol_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert out == {"clean": True, "raise": True, "fallback": True}, (rank, out)

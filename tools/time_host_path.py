@@ -1,5 +1,7 @@
 """Timing of the reference-shaped call -- NumPy box in, NumPy fields out (subbox.py:139-219) -- against the resident
-call, on one box in one process: pipelined (default), un-pipelined (NBE_HOST_PIPE=0), pinned input, CUDA tensors.
+call, on one box in one process: the reference's default call (show_progress=True: a tqdm bar fed from a host thread),
+pipelined (default), un-pipelined (NBE_HOST_PIPE=0), pinned input, CUDA tensors.  N = 1024 runs eight tiles of 512^3, pipelined
+tile by tile (tile k + 1's planes go up and tile k - 1's fields come down under tile k).
 NBE_PIPE_TRACE=1 prints the host-side timeline of every pipelined call.   python tools/time_host_path.py [N]"""
 import os, sys, time
 import numpy as np
@@ -21,7 +23,7 @@ box = np.random.default_rng(0).standard_normal((3, N, N, N), dtype=np.float32)
 def run(tag, x, n=3):
     for i in range(n):
         t0 = time.perf_counter()
-        d, v = emu.process_box(x, 0.5, 0.3, show_progress=False)
+        d, v = emu.process_box(x, 0.5, 0.3)                         # default arguments, as the reference is called
         if isinstance(d, torch.Tensor):
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
