@@ -850,6 +850,9 @@ static int check_range(nbe_ctx* c) {
     HIPCHK(hipMemcpyAsync(&bad, c->flags + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemsetAsync(c->flags + 1, 0, 4, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad & 2u)
+        return fail("brick mode: a neighbour's faces were computed with another range shift -- every rank must call "
+                    "nbe_set_input_range with the box-wide max |x| before nbe_brick_encode");
     if (bad && c->input_finite) {
         fail("non-finite values in the output of a finite input: an activation left the range of the %s arithmetic "
              "(|value| >= 65504 * 2^%d after the range shift); rerun this call with NBE_PREC_F32",
@@ -2453,7 +2456,7 @@ int64_t nbe_brick_halo_bytes(nbe_ctx* c, const int64_t bsize[3], int which) {
     if (!c || !bsize || which < 0 || which > 3) return -1;
     if (which == 3) return brick_halo_bytes(c, BRICK_H0, (int)bsize[1] + 2, (int)bsize[2] + 2);   // whole planes, wrap-around columns included
     if (which == 0) return (int64_t)c->in_chan * BRICK_RAW * bsize[1] * bsize[2] * 4;       // raw input planes, float32
-    if (which == 1) return brick_halo_bytes(c, BRICK_H1, (int)bsize[1] / 2, (int)bsize[2] / 2);
+    if (which == 1) return brick_halo_bytes(c, BRICK_H1, (int)bsize[1] / 2, (int)bsize[2] / 2) + 16;   // + the sender's range shift
     return brick_halo_bytes(c, BRICK_H2, (int)bsize[1] / 4, (int)bsize[2] / 4);
 }
 
@@ -2494,6 +2497,11 @@ int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float 
     c->sst.Dz = Dz; c->sst.vel_fac = vel_fac; c->sst.act_scale = c->act_scale; c->sst.ws = c->ws;
     const HeadOut ho{nullptr, nullptr, NBE_F32, (int)bsize[0], (int)bsize[1], (int)bsize[2], 0, 0, 0, Dz, vel_fac};
     if (network_stream(c, tin, ho, c->slab)) return 1;
+    // the last word of either face carries this rank's range shift: the receiver refuses faces computed with another one
+    const int64_t body = brick_halo_bytes(c, BRICK_H1, (int)bsize[1] / 2, (int)bsize[2] / 2);
+    unsigned bits; memcpy(&bits, &c->act_scale, 4);
+    launch_tag_word((unsigned*)((char*)send_lo + body), bits, nullptr, nullptr, 0, c->stream);
+    launch_tag_word((unsigned*)((char*)send_hi + body), bits, nullptr, nullptr, 0, c->stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2521,6 +2529,12 @@ int nbe_brick_exchange(nbe_ctx* c, const void* recv_lo, const void* recv_hi, voi
     if (brick_resume(c, 3)) return 1;
     BrickOff off{c};
     c->bio.recv_lo = recv_lo; c->bio.recv_hi = recv_hi; c->bio.send_lo = send2_lo; c->bio.send_hi = send2_hi;
+    if (c->flags) {                                               // (strict float32 contexts have no range shift: nothing to compare)
+        const int64_t body = brick_halo_bytes(c, BRICK_H1, (c->sst.H - 2) / 2, (c->sst.W - 2) / 2);
+        unsigned bits; memcpy(&bits, &c->sst.act_scale, 4);
+        launch_tag_word(nullptr, bits, (const unsigned*)((const char*)recv_lo + body), c->flags + 1, 2u, c->stream);
+        launch_tag_word(nullptr, bits, (const unsigned*)((const char*)recv_hi + body), c->flags + 1, 2u, c->stream);
+    }
     const HeadOut ho{};
     if (network_stream(c, c->sst.tin, ho, c->sst.S)) return 1;
     HIPCHK(hipGetLastError());

@@ -139,6 +139,9 @@ void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s, c
 void launch_fill_yx(const Planes& t, int pad, bool vel, hipStream_t s);
 void launch_wrap_pad(const Planes& src, const Planes& dst, int pad, bool vel, hipStream_t s, int padz = 0);
 
+// *dst = v (dst nullable); *flag |= bit when *expect_at != v (expect_at nullable)
+void launch_tag_word(unsigned* dst, unsigned v, const unsigned* expect_at, unsigned* flag, unsigned bit, hipStream_t s);
+
 // Branch probe (test instrumentation): sign bits of one stored activation tensor over a probe region.
 // The launch's output is `ext` voxels starting at x (row pitch W, plane pitch H * W, plane stride pstride, first plane g0);
 // its voxel (0,0,0) has index `org` in the frame of the oracle's tensor for this layer, periodic in y / x with `per` where > 0.

@@ -671,6 +671,16 @@ void launch_scale(const float* src, float* dst, int n, float f, hipStream_t s, c
     if (n > 0) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, src2, dst, n, f);
 }
 
+// one word at the end of an exchange buffer: written by the sender, compared by the receiver (brick mode: every rank must
+// have computed its faces with the same range shift)
+__global__ void tag_word_kernel(unsigned* dst, unsigned v, const unsigned* expect_at, unsigned* flag, unsigned bit) {
+    if (dst) *dst = v;
+    if (expect_at && *expect_at != v) atomicOr(flag, bit);
+}
+void launch_tag_word(unsigned* dst, unsigned v, const unsigned* expect_at, unsigned* flag, unsigned bit, hipStream_t s) {
+    hipLaunchKernelGGL(tag_word_kernel, dim3(1), dim3(1), 0, s, dst, v, expect_at, flag, bit);
+}
+
 // ---- branch probe (test instrumentation: include/nbe.h, "Branch probe") ---------------------------------------------
 // One thread per 32-voxel word of the probe tensor (C, n, n, nw): bit = "the LeakyReLU behind this stored activation took
 // the identity branch" = stored value > 0 (LeakyReLU keeps the sign; exactly zero is the slope branch, layers_vel.py:184-185).

@@ -102,3 +102,55 @@ def test_sharded_equals_single_process(world, size, ndiv):
     if zb and grid[1] == 1 and grid[2] == 1 and size[0] // grid[0] >= 48:
         # z-slab bricks run the single-GPU schedule of the whole box, cut along z, with the same pairing of planes: bit for bit
         assert np.array_equal(d_all, d_ref) and np.array_equal(v_all, v_ref)
+
+
+def test_brick_calls_guard_their_state(engine_factory):
+    """The C ABI's brick calls on one context (include/nbe.h, "Brick mode"): a brick survives only until another call uses
+    the context's workspace; the calls must come in order; and faces computed with another range shift are refused (the
+    sender's shift travels in the last word of either face: a sharded box whose ranks did not agree on one max |x|)."""
+    import torch
+    from jax_nbody_emulator_with_dj_amd.engine import NBEError
+    from oracle import params as P
+    Dz, vf = 0.7731811501855036, 50.537651303131064
+    e = engine_factory(mid_chan=8, compute_vel=True, precision="f16x3")
+    e.load_params(P.synthetic_params(seed=61, mid_chan=8), premodulated=False)
+    e.set_cosmology(OM, Dz)
+    b = (64, 64, 64)
+    H = torch.randn((3, b[0] + 8, b[1], b[2]), device="cuda")
+    n = [e.brick_halo_bytes(b, w) for w in (1, 2, 3)]
+    f1 = [torch.zeros(n[0], dtype=torch.uint8, device="cuda") for _ in range(4)]
+    f2 = [torch.zeros(n[1], dtype=torch.uint8, device="cuda") for _ in range(4)]
+    f3 = [torch.zeros(n[2], dtype=torch.uint8, device="cuda") for _ in range(4)]
+    disp, vel = torch.zeros((3,) + b, device="cuda"), torch.zeros((3,) + b, device="cuda")
+
+    def whole(faces_from=None):
+        e.brick_encode(H, b, Dz, vf, f1[0], f1[1], f3[0], f3[1])
+        f1[2].copy_(f1[1] if faces_from is None else faces_from[1]); f1[3].copy_(f1[0] if faces_from is None else faces_from[0])
+        f3[2].copy_(f3[1]); f3[3].copy_(f3[0])
+        e.brick_interior()
+        e.brick_exchange(f1[2], f1[3], f2[0], f2[1])
+        f2[2].copy_(f2[1]); f2[3].copy_(f2[0])
+        e.brick_finish(f2[2], f2[3], f3[2], f3[3], Dz, vf, disp, vel)
+
+    try:
+        e.set_input_range(4.0)
+        whole(); e.check_finite()                                    # a brick that is its own neighbour: fine
+        assert bool(torch.isfinite(disp).all()) and float(disp.abs().max()) > 0
+        # out of order, and after another call has used the workspace
+        with pytest.raises(NBEError, match="brick call"):
+            e.brick_interior()
+        e.brick_encode(H, b, Dz, vf, f1[0], f1[1], f3[0], f3[1])
+        with pytest.raises(NBEError, match="out of order"):
+            e.brick_exchange(f1[2], f1[3], f2[0], f2[1])
+        e.brick_encode(H, b, Dz, vf, f1[0], f1[1], f3[0], f3[1])
+        e.forward(torch.randn((3, 104, 104, 104), device="cuda"), Dz, vf)
+        with pytest.raises(NBEError, match="brick call"):
+            e.brick_interior()
+        # faces from a rank that used another range shift
+        other = [f1[0].clone(), f1[1].clone()]
+        e.set_input_range(4000.0)
+        whole(faces_from=other)
+        with pytest.raises(NBEError, match="another range shift"):
+            e.check_finite()
+    finally:
+        e.set_input_range(None)

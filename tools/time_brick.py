@@ -5,8 +5,13 @@
   output, 4 planes of the level-0 skip connection (under levels 1-3) -- here copied from the brick's own send buffers on a second stream (same bytes, same kernels, same stream
   choreography as sharding.ShardedBox._process_zbrick, no link) -- Engine.brick_encode / brick_interior / brick_exchange /
   brick_finish.
-  padded bricks (the round-1 scheme, NBE_ZBRICKS=0): haloed along the axes the rank grid splits, halo recomputed."""
+  padded bricks (the round-1 scheme, NBE_ZBRICKS=0): haloed along the axes the rank grid splits, halo recomputed.
+
+  --link GB/s   make every exchange take as long on the communication stream as that link rate would (a spin kernel behind
+                the copy): the timeline a real xGMI hop produces -- whether the compute stream ever waits for a transfer shows
+                as the difference to the run without it.  --link 0 (default): copies only."""
 import sys, time
+LINK = float(sys.argv[sys.argv.index("--link") + 1]) if "--link" in sys.argv else 0.0
 sys.path.insert(0, ".")
 import torch
 from jax_nbody_emulator_with_dj_amd.engine import Engine
@@ -42,6 +47,8 @@ for n in (1, 2, 4, 8):
         comm.wait_stream(cur)
         with torch.cuda.stream(comm):
             b_hi.copy_(a_lo); b_lo.copy_(a_hi)
+            if LINK > 0:                                           # both directions travel at once, each at the link rate
+                torch.cuda._sleep(int(a_lo.numel() / (LINK * 1e9) * 2.0e9))     # cycles of a ~2 GHz counter
             ev = torch.cuda.Event(); ev.record(comm)
         return ev
 
@@ -57,12 +64,12 @@ for n in (1, 2, 4, 8):
         cur.wait_event(ev_skip)
         e.brick_finish(r2_lo, r2_hi, q_lo, q_hi, 0.77, 50.0, disp, vel)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("N=%d z-slab brick %s, exchanges of %.0f + %.0f + %.0f + %.0f MB per direction: %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
+    print(("link emulated at %g GB/s: " % LINK if LINK > 0 else "") + "N=%d z-slab brick %s, exchanges of %.0f + %.0f + %.0f + %.0f MB per direction: %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
           % (n, b, e.brick_halo_bytes(b, 0) / 1e6, n1 / 1e6, n2 / 1e6, n3 / 1e6, dt, N ** 3 / dt / 1e6, t1 / (n * dt)), flush=True)
     del H, disp, vel, s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi, k_lo, k_hi, q_lo, q_hi
     torch.cuda.empty_cache()
 # the padded scheme of round 1 for comparison
-for name, grid in (("N=8 (2,2,2)", (2, 2, 2)), ("N=4 (4,1,1)", (4, 1, 1))):
+for name, grid in [] if LINK > 0 else (("N=8 (2,2,2)", (2, 2, 2)), ("N=4 (4,1,1)", (4, 1, 1))):
     b = tuple(N // g for g in grid)
     pa = tuple(48 if g > 1 else 0 for g in grid)
     H = torch.randn((3,) + tuple(bb + 2 * p for bb, p in zip(b, pa)), device="cuda")
