@@ -181,7 +181,9 @@ int nbe_process_region(nbe_ctx* ctx, const void* box, const int64_t box_size[3],
  *                       neighbour's send_lo): the rest of conv_l1, the skip connection, down_l1; writes the first / last
  *                       10 down_l1 planes to send2_lo / send2_hi;
  *   nbe_brick_finish    with the neighbours' second faces and their skip-connection planes: levels 2-3, the decoders, the
- *                       brick's (C, b0, S1, S2) fields.
+ *                       brick's (C, b0, S1, S2) fields.  The skip-connection planes are read last: the stream waits for
+ *                       skip_ready_event (recorded by the caller behind their transfer; NULL = they are there) only after
+ *                       levels 1-3, so that transfer is hidden under them.
  * The four calls must follow each other on one context (any other call in between invalidates the brick and the next
  * brick call fails); all are asynchronous on the context's stream -- the caller orders the exchanges against it (events).
  * EVERY RANK MUST USE THE SAME RANGE SHIFT: call nbe_set_input_range with the box-wide max |x| first (the shim all-reduces
@@ -196,7 +198,7 @@ int nbe_brick_encode(nbe_ctx* ctx, const void* haloed_brick, const int64_t brick
 int nbe_brick_interior(nbe_ctx* ctx);
 int nbe_brick_exchange(nbe_ctx* ctx, const void* recv_lo, const void* recv_hi, void* send2_lo, void* send2_hi);
 int nbe_brick_finish(nbe_ctx* ctx, const void* recv2_lo, const void* recv2_hi, const void* skip_recv_lo, const void* skip_recv_hi,
-                     float Dz, float vel_fac, void* disp, void* vel, int out_dtype);
+                     void* skip_ready_event /* hipEvent_t or NULL */, float Dz, float vel_fac, void* disp, void* vel, int out_dtype);
 
 /* Internal tiling.  When crop_size = size/ndiv is a multiple of 8 on every axis, all crop origins keep the
  * phase of the network's 2^3 stride lattice, so the per-voxel result does not depend on how the box is cut

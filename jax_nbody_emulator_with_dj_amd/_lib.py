@@ -62,7 +62,7 @@ SIGNATURES = {
     "nbe_brick_interior": (C.c_int, [C.c_void_p]),
     "nbe_brick_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nbe_brick_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "nbe_brick_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int]),
+    "nbe_brick_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int]),
     "nbe_plan_tiles": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "nbe_plan_tiles_ctx": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "nbe_set_max_tile": (C.c_int, [C.c_void_p, C.c_int]),

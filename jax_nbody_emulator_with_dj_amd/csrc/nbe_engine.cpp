@@ -168,7 +168,8 @@ struct nbe_ctx {
     bool zx = false;
     int phase = 0;                                // 0: whole schedule; 1: up to the exchange; 2: from the exchange on
     struct BrickIO { void *send_lo = nullptr, *send_hi = nullptr; const void *recv_lo = nullptr, *recv_hi = nullptr;
-                     void *skip_send_lo = nullptr, *skip_send_hi = nullptr; const void *skip_recv_lo = nullptr, *skip_recv_hi = nullptr; } bio;
+                     void *skip_send_lo = nullptr, *skip_send_hi = nullptr; const void *skip_recv_lo = nullptr, *skip_recv_hi = nullptr;
+                     hipEvent_t skip_ready = nullptr; } bio;
     struct StreamState {                          // what the next brick call resumes with (tensors in the arena, which is left alone in between)
         bool valid = false;
         int stage = 0;                            // the last phase that ran (1 encode, 2 interior, 3 edges)
@@ -1235,6 +1236,13 @@ static int stream_tail(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S, 
     if (2 * r.p.D != skip0.p.D || 2 * (r.p.H - 2 * r.pad) != skip0.p.H - 2 * pad || 2 * (r.p.W - 2 * r.pad) != skip0.p.W - 2 * pad)
         return fail("internal: level-0 concat geometry mismatch");
 
+    if (pad && c->zx && !c->dry && c->bio.skip_recv_lo) {
+        // brick mode: the neighbours' planes of the skip connection, below and above the brick's own -- the last of the four
+        // exchanges to be needed; it travelled while levels 1-3 ran, and only now does the stream wait for it
+        if (c->bio.skip_ready) HIPCHK(hipStreamWaitEvent(c->stream, c->bio.skip_ready, 0));
+        launch_crop(brick_planes(c, skip0, c->bio.skip_recv_lo, BRICK_H0), 0, zview(skip0, 0, BRICK_H0).p, 0, c->vel, c->stream, 0);
+        launch_crop(brick_planes(c, skip0, c->bio.skip_recv_hi, BRICK_H0), 0, zview(skip0, skip0.p.D - BRICK_H0, BRICK_H0).p, 0, c->vel, c->stream, 0);
+    }
     const int Yo = skip0.p.D - 8;                                 // output planes (= D - 96)
     // Persistent slab tensors of the level-0 decoder, with the same carry-over of the overlaps (8 / 6 / 4 / 2 planes of
     // the concat tensor, the hidden and the result of conv_r00, the hidden of conv_r01).
@@ -1330,10 +1338,6 @@ static int network_stream(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int 
     }
     Tensor t;
     if (brick_level2(c, st, &t)) return 1;
-    if (!c->dry && c->bio.skip_recv_lo) {                         // the neighbours' planes of the skip connection, below and above the own ones
-        launch_crop(brick_planes(c, st.skip0, c->bio.skip_recv_lo, BRICK_H0), 0, zview(st.skip0, 0, BRICK_H0).p, 0, c->vel, c->stream, 0);
-        launch_crop(brick_planes(c, st.skip0, c->bio.skip_recv_hi, BRICK_H0), 0, zview(st.skip0, st.skip0.p.D - BRICK_H0, BRICK_H0).p, 0, c->vel, c->stream, 0);
-    }
     st.valid = false;
     return stream_tail(c, st.tin, ho, st.S, st.skip0, st.cat1, t);
 }
@@ -2472,7 +2476,7 @@ int nbe_brick_plan(nbe_ctx* c, const int64_t bsize[3]) {
     return sl;
 }
 
-struct BrickOff { nbe_ctx* c; ~BrickOff() { c->phase = 0; c->zx = false; } };
+struct BrickOff { nbe_ctx* c; ~BrickOff() { c->phase = 0; c->zx = false; c->bio.skip_ready = nullptr; c->bio.skip_recv_lo = nullptr; } };
 
 int nbe_brick_encode(nbe_ctx* c, const void* box, const int64_t bsize[3], float Dz, float vel_fac, void* send_lo, void* send_hi,
                      void* skip_send_lo, void* skip_send_hi) {
@@ -2542,7 +2546,7 @@ int nbe_brick_exchange(nbe_ctx* c, const void* recv_lo, const void* recv_hi, voi
 }
 
 int nbe_brick_finish(nbe_ctx* c, const void* recv_lo, const void* recv_hi, const void* skip_recv_lo, const void* skip_recv_hi,
-                     float Dz, float vel_fac, void* disp, void* vel, int out_dtype) {
+                     void* skip_ready_event, float Dz, float vel_fac, void* disp, void* vel, int out_dtype) {
     if (!c || !recv_lo || !recv_hi || !skip_recv_lo || !skip_recv_hi || !disp) return fail("null argument");
     if (c->vel && !vel) return fail("velocity output pointer is NULL but compute_vel is set");
     if (out_dtype != NBE_F32 && out_dtype != NBE_F16) return fail("out_dtype must be NBE_F32 or NBE_F16");
@@ -2551,6 +2555,7 @@ int nbe_brick_finish(nbe_ctx* c, const void* recv_lo, const void* recv_hi, const
     if (c->sst.Dz != Dz || c->sst.vel_fac != vel_fac || c->sst.act_scale != c->act_scale)
         return fail("nbe_brick_finish: Dz, vel_fac and the range shift must be those of the nbe_brick_encode call it completes");
     c->bio.recv_lo = recv_lo; c->bio.recv_hi = recv_hi; c->bio.skip_recv_lo = skip_recv_lo; c->bio.skip_recv_hi = skip_recv_hi;
+    c->bio.skip_ready = (hipEvent_t)skip_ready_event;
     const int b0 = c->sst.D - 96, S1 = c->sst.H - 2, S2 = c->sst.W - 2;
     const HeadOut ho{disp, vel, out_dtype, b0, S1, S2, 0, 0, 0, Dz, vel_fac};
     if (network_stream(c, c->sst.tin, ho, c->sst.S)) return 1;

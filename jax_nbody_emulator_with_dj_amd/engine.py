@@ -335,12 +335,15 @@ class Engine:
         self._check_faces(self._brick, 2, send2_lo, send2_hi)
         check(self._l.nbe_brick_exchange(self._h, _ptr(recv_lo), _ptr(recv_hi), _ptr(send2_lo), _ptr(send2_hi)))
 
-    def brick_finish(self, recv2_lo, recv2_hi, skip_recv_lo, skip_recv_hi, Dz, vel_fac, disp, vel):
+    def brick_finish(self, recv2_lo, recv2_hi, skip_recv_lo, skip_recv_hi, Dz, vel_fac, disp, vel, skip_ready=None):
+        """skip_ready: a torch.cuda.Event recorded behind the transfer of the skip-connection planes (None: they are there);
+        the engine's stream waits for it only where the decoder first reads them, after levels 1-3."""
         self._follow_torch_stream(disp)
         half = disp.element_size() == 2
         self._check_faces(self._brick, 2, recv2_lo, recv2_hi)
         self._check_faces(self._brick, 3, skip_recv_lo, skip_recv_hi)
-        check(self._l.nbe_brick_finish(self._h, _ptr(recv2_lo), _ptr(recv2_hi), _ptr(skip_recv_lo), _ptr(skip_recv_hi),
+        ev = C.c_void_p(skip_ready.cuda_event) if skip_ready is not None else None
+        check(self._l.nbe_brick_finish(self._h, _ptr(recv2_lo), _ptr(recv2_hi), _ptr(skip_recv_lo), _ptr(skip_recv_hi), ev,
                                        float(Dz), float(vel_fac), _ptr(disp), _ptr(vel), 1 if half else 0))
 
     # ---- test hooks ---------------------------------------------------------------------------

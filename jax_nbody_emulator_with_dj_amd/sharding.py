@@ -262,16 +262,17 @@ class ShardedBox:
         s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi, k_lo, k_hi, q_lo, q_hi = self._halo
         self.eng.brick_encode(H, self.bshape, Dz, vel_fac, s_lo, s_hi, k_lo, k_hi)
         ev = self._exchange_async(cur, s_lo, s_hi, r_lo, r_hi)
-        ev_skip = self._exchange_async(cur, k_lo, k_hi, q_lo, q_hi)   # the skip connection's planes: needed by the decoder only
         self.eng.brick_interior()                                   # runs while the faces travel
         if ev is not None:
             cur.wait_event(ev)
         self.eng.brick_exchange(r_lo, r_hi, s2_lo, s2_hi)
         ev = self._exchange_async(cur, s2_lo, s2_hi, r2_lo, r2_hi)
-        for e in (ev, ev_skip):
-            if e is not None:
-                cur.wait_event(e)
-        self.eng.brick_finish(r2_lo, r2_hi, q_lo, q_hi, Dz, vel_fac, disp, vel)
+        # the skip connection's planes go last on the communication stream (behind the faces the compute stream is waiting
+        # for) and are needed last: the engine waits for them after levels 1-3, inside brick_finish
+        ev_skip = self._exchange_async(cur, k_lo, k_hi, q_lo, q_hi)
+        if ev is not None:
+            cur.wait_event(ev)
+        self.eng.brick_finish(r2_lo, r2_hi, q_lo, q_hi, Dz, vel_fac, disp, vel, skip_ready=ev_skip)
 
     def _agree_on_bricks(self, device):
         """A brick whose workspace does not fit the memory that is free now runs as padded bricks instead; every rank must

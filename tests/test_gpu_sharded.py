@@ -130,7 +130,7 @@ def test_brick_calls_guard_their_state(engine_factory):
         e.brick_interior()
         e.brick_exchange(f1[2], f1[3], f2[0], f2[1])
         f2[2].copy_(f2[1]); f2[3].copy_(f2[0])
-        e.brick_finish(f2[2], f2[3], f3[2], f3[3], Dz, vf, disp, vel)
+        e.brick_finish(f2[2], f2[3], f3[2], f3[3], Dz, vf, disp, vel)          # (no event: the planes are there)
 
     try:
         e.set_input_range(4.0)

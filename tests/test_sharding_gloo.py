@@ -184,7 +184,7 @@ class _FakeEngine:
         s2_lo.fill_(10 * self.rank + 3); s2_hi.fill_(10 * self.rank + 4)
         self.calls.append("exchange")
 
-    def brick_finish(self, r2_lo, r2_hi, q_lo, q_hi, Dz, vf, disp, vel):
+    def brick_finish(self, r2_lo, r2_hi, q_lo, q_hi, Dz, vf, disp, vel, skip_ready=None):
         minus, plus = (self.rank - 1) % self.world, (self.rank + 1) % self.world
         assert bool((r2_lo == 10 * minus + 4).all()) and bool((r2_hi == 10 * plus + 3).all())
         assert bool((q_lo == 10 * minus + 6).all()) and bool((q_hi == 10 * plus + 5).all())

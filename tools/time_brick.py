@@ -56,13 +56,13 @@ for n in (1, 2, 4, 8):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         e.brick_encode(H, b, 0.77, 50.0, s_lo, s_hi, k_lo, k_hi)
         ev = exchange(s_lo, s_hi, r_lo, r_hi)
-        ev_skip = exchange(k_lo, k_hi, q_lo, q_hi)
         e.brick_interior()
         cur.wait_event(ev)
         e.brick_exchange(r_lo, r_hi, s2_lo, s2_hi)
-        cur.wait_event(exchange(s2_lo, s2_hi, r2_lo, r2_hi))
-        cur.wait_event(ev_skip)
-        e.brick_finish(r2_lo, r2_hi, q_lo, q_hi, 0.77, 50.0, disp, vel)
+        ev2 = exchange(s2_lo, s2_hi, r2_lo, r2_hi)
+        ev_skip = exchange(k_lo, k_hi, q_lo, q_hi)               # last on the communication stream, needed last
+        cur.wait_event(ev2)
+        e.brick_finish(r2_lo, r2_hi, q_lo, q_hi, 0.77, 50.0, disp, vel, skip_ready=ev_skip)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(("link emulated at %g GB/s: " % LINK if LINK > 0 else "") + "N=%d z-slab brick %s, exchanges of %.0f + %.0f + %.0f + %.0f MB per direction: %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
           % (n, b, e.brick_halo_bytes(b, 0) / 1e6, n1 / 1e6, n2 / 1e6, n3 / 1e6, dt, N ** 3 / dt / 1e6, t1 / (n * dt)), flush=True)
