@@ -115,7 +115,7 @@ def source_hash():
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into libnbe.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "nbe_kernels.h"), os.path.join(CSRC, "nbe_kernels_internal.h"), os.path.join(CSRC, "nbe_kernels_wino.h"), os.path.join(_HERE, "..", "include", "nbe.h")]
+    deps = srcs + [os.path.join(CSRC, "nbe_kernels.h"), os.path.join(CSRC, "nbe_kernels_internal.h"), os.path.join(CSRC, "nbe_kernels_wino.h"), os.path.join(CSRC, "nbe_kernels_head.h"), os.path.join(_HERE, "..", "include", "nbe.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
             return LIB_PATH

@@ -1434,7 +1434,7 @@ static int run_tile(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0
     // (the A/B switches that launchers read per launch are part of the key: a captured graph holds the kernels they chose)
     auto sw = [](const char* n, int bit) { const char* e = getenv(n); return (e && atoi(e) == 0) ? (1 << bit) : 0; };
     k.epoch = c->epoch; k.flags = (c->pyx ? 1 : 0) | (c->pz ? 2 : 0) | (c->gauge_active ? 4 : 0) | (c->fuse ? 8 : 0) |
-              sw("NBE_WINO", 4) | sw("NBE_UP8", 5) | sw("NBE_STEM", 6) | sw("NBE_H3G_TALL", 7) | sw("NBE_NARROW", 8);
+              sw("NBE_WINO", 4) | sw("NBE_UP8", 5) | sw("NBE_STEM", 6) | sw("NBE_H3G_TALL", 7) | sw("NBE_NARROW", 8) | sw("NBE_HEAD4", 9);
     nbe_ctx::GraphVal& g = c->graphs[k];
     g.used = ++c->graph_clock;
     if (!g.exec && g.seen++ == 0) {                              // first time: eager

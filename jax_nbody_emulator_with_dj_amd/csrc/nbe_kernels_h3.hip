@@ -1571,6 +1571,7 @@ static int launch_h3g(ConvKArgs ka, int ctiles, hipStream_t s) {
 }
 
 #include "nbe_kernels_wino.h"
+#include "nbe_kernels_head.h"
 
 // ------------------------------------------------------------------------------------------------
 // The two-accumulator variants on the 16x16x32 shape: f16x3 without velocity and plain f16 with velocity
@@ -2178,7 +2179,11 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         if (!(pw.mode == MODE_FLAT3 && vel && has_dx && ka.in_off == 0 && ka.osz == 1)) return 1;   // no gauged kernel
         if (split) {
             const bool tall = !(getenv("NBE_H3G_TALL") && atoi(getenv("NBE_H3G_TALL")) == 0);   // A/B switch, default on (read per launch)
-            if (pw.cout_t == 16) return launch_h3g<true, false>(ka, ct, s);
+            if (pw.cout_t == 16) {                              // the head convolution: four output planes per workgroup where the launch allows
+                const bool head4 = !(getenv("NBE_HEAD4") && atoi(getenv("NBE_HEAD4")) == 0);   // A/B switch, default on (read per launch)
+                if (head4 && launch_h3n4(ka, ct, s) == 0) return 0;
+                return launch_h3g<true, false>(ka, ct, s);
+            }
 #if NBE_DBG
             if (getenv("NBE_H3G_BIG") && atoi(getenv("NBE_H3G_BIG")) == 1) return launch_h3g<false, false, true>(ka, ct, s);   // 4 x 4 wave tile, one wave per SIMD
 #endif

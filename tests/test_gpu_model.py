@@ -116,11 +116,11 @@ def test_gauged_tangent_paths(engine_factory, small, monkeypatch, prec):
     _check(dt, vt, dt_o[0], vt_o[0], "tiny style factor")
 
 
-@pytest.mark.parametrize("switch", ["NBE_H3G_TALL", "NBE_STEM", "NBE_UP8", "NBE_NARROW", "NBE_WINO"])
+@pytest.mark.parametrize("switch", ["NBE_H3G_TALL", "NBE_STEM", "NBE_UP8", "NBE_NARROW", "NBE_HEAD4", "NBE_WINO"])
 def test_kernel_ab_switches_keep_parity(engine_factory, small, monkeypatch, switch):
     """Every A/B switch of the f16x3 velocity path selects kernels that stay held to the oracle: the 2 x 4 wave tile of
     conv_h3g_kernel (its zero-select once sat next to an asm MFMA, tests/test_mfma_hazards.py), the general first-layer kernel,
-    eight up-sampling launches, the wide tile for the head, and the direct gauged
+    eight up-sampling launches, the wide tile for the head, one output plane per workgroup on the narrow tile, and the direct gauged
     kernel in place of the Winograd-z one (conv_h3w_kernel)."""
     p, x, d_o, v_o = small
     monkeypatch.setenv(switch, "0")
