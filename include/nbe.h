@@ -101,7 +101,13 @@ enum { NBE_Q_GAUGE_ACTIVE = 0,     /* 1: the loaded weights run the two-product 
        NBE_Q_RANGE_SHIFT = 4,      /* k of the last call's range shift 2^k                                            */
        NBE_Q_WORKSPACE_BYTES = 5,
        NBE_Q_HOST_PIPE = 6,        /* 1: the last nbe_process_box call ran the pipelined host path (nbe_host_alloc)    */
-       NBE_Q_GRAPH_REPLAYS = 7 };  /* tiles replayed from a captured hipGraph so far (see below)                       */
+       NBE_Q_GRAPH_REPLAYS = 7,    /* tiles replayed from a captured hipGraph so far (see below)                       */
+       NBE_Q_PLAN_TILES = 8,       /* tiles per box of the last plan                                                    */
+       NBE_Q_PLAN_SHORT_GB = 9 };  /* > 0: the last plan is NOT the largest exact merge (max_tile permitting) because its
+                                      workspace did not fit: GB of device memory that were missing.  The engine also
+                                      writes one line to stderr when that happens (NBE_QUIET=1 silences it): the 512^3
+                                      box as one tile needs ~200 GB free beside the box and the fields; with less the
+                                      planner takes two, four or eight tiles and runs 1.1 - 1.4 x slower.              */
 /* hipGraph replay.  A tile of nbe_process_box / nbe_process_region with device pointers in and out enqueues a few
  * hundred launches (the reference's analogue is the jitted step, subbox.py:137).  The second time the identical tile is
  * requested -- same pointers, geometry, scalars, weights and modulation -- its schedule is captured (on the context's

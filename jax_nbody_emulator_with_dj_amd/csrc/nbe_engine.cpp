@@ -187,6 +187,9 @@ struct nbe_ctx {
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
     bool fuse = false;                            // ... and the blocks' skips run fused into their conv_1 (f16x3 only)
     bool novel_fuse = false;                      // displacement-only f16x3: the blocks are wired for conv_h3w_kernel<SKIP, NOVEL>
+    int plan_tiles = 0;                           // tiles per box of the last plan (nbe_query)
+    double plan_short_gb = 0.0;                   // > 0: a larger exact merge existed but its workspace lacked this much memory
+    int64_t plan_logged = 0;                      // the situation the last stderr line was about (one line per situation)
     int* gauge_flag = nullptr;                    // device flag of launch_style_alpha
     // Winograd-z form of the gauged 3x3x3 layers (conv_h3w_kernel): packed beside pw.w for every gauged wide layer;
     // wino_ok is cleared when a weight of the current modulation leaves the f16 range at the kernel's 2^14 scale
@@ -211,6 +214,8 @@ struct nbe_ctx {
     struct HostPipe {
         bool active = false, out_async = false;
         bool tiles = false;                       // several tiles: tile k+1's planes go up and tile k-1's results come down under tile k
+        bool slabwise = false;                    // ... and the running tile gathers slab by slab as its planes land (z-slab schedule)
+        int o1 = 0, o2 = 0;                       // y / x origin of the running tile's gather (tiles mode; the one-tile plan: -halo)
         const float* hbox = nullptr;              // caller's (C, S0, S1, S2) array
         bool in_pinned = false;
         int C = 0, S0 = 0, S1 = 0, S2 = 0, o0 = 0;    // o0: box plane of tile plane 0 (may be negative: periodic)
@@ -916,7 +921,8 @@ static int pipe_input(nbe_ctx* c, const Tensor& tin, int t0, int t1, int look, f
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_up, 0));
         const Tensor v = zview(tin, P.gz, t1 - P.gz);
         const int h = tin.pad ? 1 : 48;
-        launch_gather(c->box_in, P.C, P.S0, P.S1, P.S2, P.o0 + P.gz, -h, -h, v.p, scale, c->prec, c->stream);
+        launch_gather(c->box_in, P.C, P.S0, P.S1, P.S2, P.o0 + P.gz, P.slabwise ? P.o1 : -h, P.slabwise ? P.o2 : -h, v.p, scale,
+                      c->prec, c->stream);
         P.gz = t1;
     }
     return look > 0 ? pipe_upload(c, t1, t1 + look) : 0;
@@ -1005,12 +1011,12 @@ static int stream_encode(nbe_ctx* c, const Tensor& tin, const HeadOut& ho, int S
     // upload has landed; the decoder's last slab is short for the same reason at the other end (its copy to the host is
     // the only one nothing hides).  Slabs start on even planes either way, so the fields do not change.
     for (int z = zlo, n = 0; z < zhi; z += n) {
-        n = std::min((c->pipe.active && z == zlo) ? std::min(S, PIPE_EDGE) : S, zhi - z);
+        n = std::min(((c->pipe.active || c->pipe.slabwise) && z == zlo) ? std::min(S, PIPE_EDGE) : S, zhi - z);
         const int n_next = std::min(S, zhi - (z + n));
         const bool first = z == zlo;
         // periodic in z: the slab is exactly planes [z - 40, z - 40 + n) of the skip connection -- write it there
         Tensor y0 = pz ? zview(skip0, z - 40, n) : zview(y0r, 0, n);
-        if (c->pipe.active && !c->dry && pipe_input(c, tin, z, z + n + 8, n_next, ho.Dz / 6.0f * c->act_scale)) return 1;
+        if ((c->pipe.active || c->pipe.slabwise) && !c->dry && pipe_input(c, tin, z, z + n + 8, n_next, ho.Dz / 6.0f * c->act_scale)) return 1;
         // frames (branch probe): plane j of the persistent slab tensors is plane z + j of the layer's whole tensor
         { int og[3]; org_conv(zview(tin, z, n + 8), 2, og); set_org(a, og[0], og[1], og[2]);
           org_conv(a, 2, og); set_org(y0, og[0], og[1], og[2]); }
@@ -1396,7 +1402,7 @@ static int run_subbox(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int 
     tin.pad = c->pyx ? 1 : 0;                                   // periodic-yx: (H, W) = box extent + 2, gathered from origin - 1
     if (tin.pad) set_org(tin, 0, 48, 48);                        // its interior sits 48 voxels into the padded frame
     // core :132-134: x = x * (Dz / 6); the pipelined host path gathers slab by slab as the box arrives (pipe_input)
-    if (!c->pipe.active)
+    if (!c->pipe.active && !c->pipe.slabwise)
         launch_gather(box, c->in_chan, Db, Hb, Wb, o0, o1, o2, tin.p, Dz / 6.0f * c->act_scale, c->prec, c->stream);
     const HeadOut ho{disp, velo, out_dtype, OD, OH, OW, a0, a1, a2, Dz, vel_fac};
     if (c->slab > 0) return network_stream(c, tin, ho, c->slab);
@@ -1423,7 +1429,7 @@ static int run_tile(nbe_ctx* c, const float* box, int Db, int Hb, int Wb, int o0
                     int D, int H, int W, float Dz, float vel_fac, void* disp, void* velo, int out_dtype,
                     int OD, int OH, int OW, int a0, int a1, int a2) {
     const bool off = getenv("NBE_GRAPH") && atoi(getenv("NBE_GRAPH")) == 0;
-    if (off || c->prof || c->prog_cb || c->pipe.active || c->dry || c->probe.on)
+    if (off || c->prof || c->prog_cb || c->pipe.active || c->pipe.slabwise || c->dry || c->probe.on)
         return run_subbox(c, box, Db, Hb, Wb, o0, o1, o2, D, H, W, Dz, vel_fac, disp, velo, out_dtype, OD, OH, OW, a0, a1, a2);
     nbe_ctx::GraphKey k;
     memset(&k, 0, sizeof k);
@@ -2099,7 +2105,7 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
         crop[a] = region[a] / ndiv[a];
         if (crop[a] % 8 != 0 || crop[a] * ndiv[a] != region[a]) return 0;      // merging would not be exact
     }
-    int64_t best_vol = 0, best_w = 0;
+    int64_t best_vol = 0, best_w = 0, miss_vol = 0, miss_need = 0;
     for (int m0 = 1; m0 <= ndiv[0]; ++m0) {
         if (ndiv[0] % m0 || crop[0] * m0 > c->max_tile) continue;
         for (int m1 = 1; m1 <= ndiv[1]; ++m1) {
@@ -2110,7 +2116,20 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
                 const int64_t w = e2 * 1000000 + e1 * 1000 + e0;               // tie-break: long last axis
                 if (vol < best_vol || (vol == best_vol && w <= best_w)) continue;
                 int sl = 0; bool px = false;
-                if (!schedule(e0, e1, e2, m1 == ndiv[1] && m2 == ndiv[2], &sl, &px)) { (void)nbe_last_error(); continue; }
+                if (!schedule(e0, e1, e2, m1 == ndiv[1] && m2 == ndiv[2], &sl, &px)) {
+                    (void)nbe_last_error();
+                    if (vol > miss_vol) {                        // what the largest merge that did not fit would have needed
+                        const bool spans = m1 == ndiv[1] && m2 == ndiv[2] && full_yx;
+                        const bool kp = c->pyx, kz = c->pz; const int ks_ = c->slab;
+                        c->pyx = spans; c->pz = spans && full_z && e0 == region[0]; c->slab = 32;
+                        const int ext = spans ? 2 : 96;
+                        const int64_t need = workspace_need(c, (int)e0 + 96, (int)e1 + ext, (int)e2 + ext);
+                        c->pyx = kp; c->pz = kz; c->slab = ks_;
+                        (void)nbe_last_error();
+                        if (need > 0) { miss_vol = vol; miss_need = need; }
+                    }
+                    continue;
+                }
                 best_vol = vol; best_w = w; best_slab = sl; best_pyx = px;
                 out_ndiv[0] = ndiv[0] / m0; out_ndiv[1] = ndiv[1] / m1; out_ndiv[2] = ndiv[2] / m2;
             }
@@ -2118,6 +2137,20 @@ static int plan_tiles_mem(nbe_ctx* c, const int64_t region[3], const int ndiv[3]
     }
     c->slab = best_slab; c->pyx = best_pyx;
     c->pz = best_pyx && full_z && out_ndiv[0] == 1;
+    c->plan_tiles = out_ndiv[0] * out_ndiv[1] * out_ndiv[2];
+    c->plan_short_gb = 0.0;
+    if (miss_vol > best_vol) {                                   // a larger exact merge exists and only memory kept the planner from it
+        c->plan_short_gb = std::max(0.0, (double)(miss_need - budget) / 1e9);
+        static const bool quiet = getenv("NBE_QUIET") && atoi(getenv("NBE_QUIET")) != 0;
+        const int64_t key = miss_vol * 1000 + c->plan_tiles;
+        if (!quiet && key != c->plan_logged) {
+            fprintf(stderr, "nbe: box %lld x %lld x %lld runs as %d x %d x %d tiles: a larger tile needs at least %.0f GB of workspace (even in "
+                            "32-plane slabs), %.0f GB are free for it on device %d -- expect 1.1 - 1.4 x the time of the larger plan\n",
+                    (long long)region[0], (long long)region[1], (long long)region[2], out_ndiv[0], out_ndiv[1], out_ndiv[2],
+                    miss_need / 1e9, budget / 1e9, c->device);
+            c->plan_logged = key;
+        }
+    }
     return 0;
 }
 
@@ -2238,7 +2271,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     const bool pipe_off = getenv("NBE_HOST_PIPE") && atoi(getenv("NBE_HOST_PIPE")) == 0;   // read per call: A/B in one process
     auto& P = c->pipe;
     P.active = false;
-    P.tiles = false;
+    P.tiles = false; P.slabwise = false;
     const bool whole_box = S0 == O0 && S1 == O1 && S2 == O2 && oorigin[0] == 0 && oorigin[1] == 0 && oorigin[2] == 0 &&
                            origin[0] == 0 && origin[1] == 0 && origin[2] == 0 && region[0] == S0 && region[1] == S1 && region[2] == S2;
     const bool one_tile = c->slab > 0 && c->pyx && c->pz && ndiv[0] * ndiv[1] * ndiv[2] == 1;
@@ -2268,7 +2301,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
             c->stage_bytes = sb;
         }
     }
-    struct PipeGuard { nbe_ctx::HostPipe& p; ~PipeGuard() { p.active = false; p.tiles = false; } } pipe_guard{P};
+    struct PipeGuard { nbe_ctx::HostPipe& p; ~PipeGuard() { p.active = false; p.tiles = false; p.slabwise = false; } } pipe_guard{P};
     c->last_piped = P.active || P.tiles;
     const bool piped = P.active || P.tiles;
     if (!in_dev) {
@@ -2304,10 +2337,14 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
     if (cb) reporter.reset(new Progress(cb, user, c->device));
     struct ProgGuard { nbe_ctx* c; ~ProgGuard() { c->prog = nullptr; c->prog_cb = nullptr; } } prog_guard{c};
     c->prog = reporter.get();
+    // tiles in the z-slab schedule gather slab by slab as their planes land (the first tile of a 1024^3 box would otherwise
+    // wait for 608 planes = 7.6 GB before its first kernel)
+    P.slabwise = P.tiles && c->slab > 0;
     if (P.tiles) {
-        // the first tile's planes, then max|x| on the host while the DMA runs
+        // the first tile's (first slab's) planes, then max|x| on the host while the DMA runs
         P.o0 = -48;
-        if (pipe_upload(c, 0, D)) return 1;
+        const int zs = c->pyx && c->pz ? 40 : 0;
+        if (P.slabwise ? pipe_upload(c, zs, zs + std::min(c->slab, PIPE_EDGE) + 8) : pipe_upload(c, 0, D)) return 1;
         t_up0 = ms_since();
         if (prepare_range(c, nullptr, (int64_t)c->in_chan * S0 * S1 * S2, Dz, (const float*)box)) return 1;
         t_range = ms_since();
@@ -2327,10 +2364,12 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
         const int a0 = (idx / (ndiv[1] * ndiv[2])) * c0, a1 = ((idx / ndiv[2]) % ndiv[1]) * c1, a2 = (idx % ndiv[2]) * c2;
         c->prog_cb = cb; c->prog_user = user; c->prog_k = k; c->prog_n = n;
         if (P.tiles) {                                           // this tile's planes (most were sent under the tile before)
-            P.o0 = a0 - 48;
-            if (pipe_upload(c, 0, D)) return 1;
-            HIPCHK(hipEventRecord(c->ev_up, c->up_stream));
-            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_up, 0));
+            P.o0 = a0 - 48; P.o1 = a1 - hal; P.o2 = a2 - hal; P.gz = 0;
+            if (!P.slabwise) {
+                if (pipe_upload(c, 0, D)) return 1;
+                HIPCHK(hipEventRecord(c->ev_up, c->up_stream));
+                HIPCHK(hipStreamWaitEvent(c->stream, c->ev_up, 0));
+            }
         }
         if (c->probe.on) {                                       // branch probe: armed for the tile that holds the block
             auto& Pb = c->probe;
@@ -2349,7 +2388,7 @@ static int process_region(nbe_ctx* c, const void* box, const int64_t bsize[3], c
             if (k + 1 < n) {                                     // the next tile's planes go up under this tile's kernels
                 const int idn = k + 1;
                 P.o0 = (idn / (ndiv[1] * ndiv[2])) * c0 - 48;
-                if (pipe_upload(c, 0, D)) return 1;
+                if (pipe_upload(c, 0, D)) return 1;              // (what this tile's slabs have not already brought up)
             }
         }
         if (reporter) reporter->post(piped && P.out_async ? c->down_stream : c->stream, (k + 1) * 1000, n * 1000);
@@ -2586,6 +2625,8 @@ int nbe_query(nbe_ctx* c, int what, double* out) {
     case NBE_Q_WORKSPACE_BYTES: *out = (double)c->ws_bytes; break;
     case NBE_Q_HOST_PIPE: *out = c->last_piped ? 1 : 0; break;
     case NBE_Q_GRAPH_REPLAYS: *out = (double)c->graph_replays; break;
+    case NBE_Q_PLAN_TILES: *out = (double)c->plan_tiles; break;
+    case NBE_Q_PLAN_SHORT_GB: *out = c->plan_short_gb; break;
     default: return fail("nbe_query: unknown item %d", what);
     }
     return 0;

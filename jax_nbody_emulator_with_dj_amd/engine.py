@@ -187,7 +187,7 @@ class Engine:
         check(self._l.nbe_synchronize(self._h))
 
     QUERY = {"gauge_active": 0, "slab": 1, "periodic_yx": 2, "periodic_z": 3, "range_shift": 4, "workspace_bytes": 5,
-             "host_pipe": 6, "graph_replays": 7}
+             "host_pipe": 6, "graph_replays": 7, "plan_tiles": 8, "plan_short_gb": 9}
 
     def query(self, what):
         """State of the context after the last call / plan (include/nbe.h, nbe_query)."""

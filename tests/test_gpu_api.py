@@ -534,3 +534,32 @@ def test_unsupported_shapes_raise():
         m.apply(p, np.zeros((1, 3, 100, 104, 104), np.float32), np.array([0.3]), np.array([1.0]))
     with pytest.raises(Exception, match="channels"):
         m.apply(p, np.zeros((1, 2, 104, 104, 104), np.float32), np.array([0.3]), np.array([1.0]))
+
+
+def test_planner_reports_when_memory_keeps_it_from_the_one_tile_plan(capfd):
+    """The timed plan of the 512^3 box (one periodic tile, ~200 GB of workspace) needs a free card.  With less memory the
+    planner takes more, smaller tiles -- 1.1 to 1.4 x slower -- and says so: nbe_query(NBE_Q_PLAN_SHORT_GB) and one line
+    on stderr, instead of silently."""
+    import torch
+    from jax_nbody_emulator_with_dj_amd.engine import Engine
+    J.models.release_engines()
+    torch.cuda.empty_cache()
+    m = J.StyleNBodyEmulatorVelCore()
+    e = Engine(device=0, compute_vel=True, precision="f16x3")
+    hog = None
+    try:
+        e.load_params(m.init(1234), premodulated=False)
+        e.set_cosmology(OM, 0.77)
+        free = torch.cuda.mem_get_info()[0]
+        if free > 240e9:
+            assert e.plan_tiles((512,) * 3, (4,) * 3) == (1, 1, 1)
+            assert e.query("plan_tiles") == 1.0 and e.query("plan_short_gb") == 0.0
+        hog = torch.empty(int(max(free - 120e9, 1e9)), dtype=torch.uint8, device="cuda")    # leave ~120 GB
+        plan = e.plan_tiles((512,) * 3, (4,) * 3)
+        err = capfd.readouterr().err
+        assert int(np.prod(plan)) > 1 and e.query("plan_tiles") == float(np.prod(plan))
+        assert e.query("plan_short_gb") > 0.0 and "a larger tile needs" in err, (plan, err)
+    finally:
+        del hog
+        e.close()
+        torch.cuda.empty_cache()

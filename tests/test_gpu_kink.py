@@ -56,6 +56,8 @@ SCHEDULES = [
 @pytest.mark.parametrize("sched", SCHEDULES, ids=[s[0] for s in SCHEDULES])
 def test_probe_and_cone_oracle_through_every_schedule(engine_factory, prec, sched):
     _, ndiv, max_tile, periodic, slab, origins = sched
+    if prec == "f32" and sched is not SCHEDULES[0]:
+        pytest.skip("the probe's frames do not depend on the arithmetic: strict float32 walks the first schedule only")
     mid, size = 8, (128, 64, 64)
     p = _synthetic(81, mid)
     box = np.random.default_rng(82).standard_normal((3,) + size).astype(np.float32)
@@ -79,7 +81,7 @@ def test_probe_on_a_single_input_and_a_larger_block(engine_factory):
     mid = 8
     p = _synthetic(83, mid)
     x = np.random.default_rng(84).standard_normal((3, 136, 120, 128)).astype(np.float32)
-    for prec in ("f16x3", "f32"):
+    for prec in ("f16x3",):
         e = engine_factory(mid_chan=mid, compute_vel=True, precision=prec)
         e.load_params(p, premodulated=False)
         e.set_cosmology(OM, DZ)
