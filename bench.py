@@ -172,15 +172,17 @@ def main():
         else:
             sb = sharding.ShardedBox(eng, size, ndiv, rank, world, comm_stream=torch.cuda.Stream(device=dev))
             step = lambda: sb.process(data, Dz, vf, disp, velo)
-            if sb.zbricks:
-                plan = "one z-slab brick %s per rank, level-1 activations exchanged (sharding.py)" % (sb.bshape,)
-            else:
-                plan = "%s tiles per rank brick" % (eng.plan_tiles(sb.bshape, sb.nd_local, periodic_box=False),)
+            plan = None
         # with --warmup 0 one priming pass still runs untimed: the first pass of a process plans the tiles and allocates
         # and zero-fills a ~200 GB workspace (seconds), which is set-up, not the hot path
         for _ in range(max(warmup, 1)):
             step()
         fence()
+        if plan is None:                          # (after the first step: the ranks agree on brick mode there, sharding.py)
+            if sb.zbricks:
+                plan = "one z-slab brick %s per rank, four face exchanges with the z neighbours (sharding.py)" % (sb.bshape,)
+            else:
+                plan = "%s padded tiles per rank brick %s" % (eng.plan_tiles(sb.bshape, sb.nd_local, periodic_box=False), sb.bshape)
         eng.debug_phase_cycles()                  # timing-probe builds: reset the in-kernel phase counters
         eng.profile_reset()
         eng.profile_enable(not args.no_profile)

@@ -187,6 +187,7 @@ struct nbe_ctx {
     bool gauge_active = false;                    // ... and the current modulation uses them (no style factor is zero)
     bool fuse = false;                            // ... and the blocks' skips run fused into their conv_1 (f16x3 only)
     bool novel_fuse = false;                      // displacement-only f16x3: the blocks are wired for conv_h3w_kernel<SKIP, NOVEL>
+    int64_t bp_size[3] = {0, 0, 0}; int bp_slab = 0; int64_t bp_need = 0;   // the brick plan that nbe_brick_plan / nbe_brick_encode last made
     int plan_tiles = 0;                           // tiles per box of the last plan (nbe_query)
     double plan_short_gb = 0.0;                   // > 0: a larger exact merge existed but its workspace lacked this much memory
     int64_t plan_logged = 0;                      // the situation the last stderr line was about (one line per situation)
@@ -2486,11 +2487,19 @@ static int brick_setup(nbe_ctx* c, const int64_t bsize[3], int* D, int* H, int* 
     if (check_dims_pyx(*D, *H, *W)) return 1;
     HIPCHK(hipSetDevice(c->device));
     c->pyx = true; c->pz = false; c->zx = true;
+    // a brick of this size has been planned before and its workspace is still held (nbe_brick_plan allocates it): the same plan,
+    // whatever the other tenants of the card have allocated since
+    if (c->bp_slab > 0 && c->bp_size[0] == b0 && c->bp_size[1] == S1 && c->bp_size[2] == S2 && c->ws_bytes >= c->bp_need) {
+        c->slab = c->bp_slab;
+        if (need_out) *need_out = c->bp_need;
+        return 0;
+    }
     const int64_t budget = plan_budget(c, 0);
     int64_t need = 0;
     const int sl = choose_slab(c, *D, *H, *W, budget < 0 ? INT64_MAX / 4 : budget, &need, true, false);
     if (sl <= 0) { c->zx = false; return fail("brick of %lld x %lld x %lld does not fit the device memory that is free", (long long)b0, (long long)S1, (long long)S2); }
     c->slab = sl; c->pyx = true; c->pz = false;
+    c->bp_size[0] = b0; c->bp_size[1] = S1; c->bp_size[2] = S2; c->bp_slab = sl; c->bp_need = need;
     if (need_out) *need_out = need;
     return 0;
 }
@@ -2508,7 +2517,10 @@ int nbe_brick_plan(nbe_ctx* c, const int64_t bsize[3]) {
     if (!c || !bsize) return 0;
     int D, H, W;
     const int keep_slab = c->slab; const bool kp = c->pyx, kz = c->pz;
-    const int rc = brick_setup(c, bsize, &D, &H, &W);
+    int rc = brick_setup(c, bsize, &D, &H, &W);
+    // take the workspace now: what is free when the first brick is encoded may be less (other ranks of a shared card, the
+    // caller's exchange buffers), and the ranks must not part ways after they have agreed on brick mode
+    if (!rc) { rc = ensure_workspace(c, D, H, W); if (rc) { c->bp_slab = 0; (void)hipGetLastError(); } }
     const int sl = rc ? 0 : c->slab;
     c->zx = false; c->slab = keep_slab; c->pyx = kp; c->pz = kz;
     (void)nbe_last_error();

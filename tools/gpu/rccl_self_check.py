@@ -4,7 +4,8 @@ grouped P2P pattern of the halo exchanges (batch_isend_irecv with both neighbour
 from self inside one group, as at world_size 2 where minus == plus), CUDA tensors, side communication stream.
 
 RCCL refuses several ranks per device, so N > 1 cannot run here; this checks that the call sequence itself is accepted by RCCL
-and ordered correctly against the compute stream.  Run:  python tools/gpu/rccl_self_check.py"""
+and ordered correctly against the compute stream -- and then runs the whole brick step of ShardedBox over RCCL with this rank as
+both of its own z neighbours (brick_protocol_with_itself_as_neighbour), against process_box of the same box.  Run:  python tools/gpu/rccl_self_check.py"""
 import os
 import sys
 
@@ -53,8 +54,44 @@ def main():
     H.record_stream(cur)
     assert H.shape == (3, 160, 144, 144) and bool(torch.isfinite(H).all())
     torch.cuda.synchronize()
+    brick_protocol_with_itself_as_neighbour(dev)
     dist.destroy_process_group()
     print("rccl self check: ok")
+
+
+def brick_protocol_with_itself_as_neighbour(dev):
+    """The whole z-slab brick step of ShardedBox over RCCL -- four face exchanges as grouped P2P on the communication stream,
+    events into the engine's stream, the skip-connection planes waited for inside nbe_brick_finish -- with ONE rank that is its
+    own z-minus and z-plus neighbour (a rank grid of (2,1,1) whose two ranks are this process: what world_size 2 does, where
+    minus == plus as well).  A brick that is its own neighbour is the periodic box, so the fields must be those of process_box."""
+    import numpy as np
+    from jax_nbody_emulator_with_dj_amd.engine import Engine
+    from oracle import params as P
+    size = (64, 64, 64)
+    eng = Engine(device=0, mid_chan=8, compute_vel=True, precision="f16x3")
+    eng.load_params(P.synthetic_params(seed=61, mid_chan=8), premodulated=False)
+    Dz, vf = 0.7731811501855036, 50.537651303131064
+    eng.set_cosmology(0.3, Dz)
+    box = torch.randn((3,) + size, device=dev)
+    d_ref, v_ref = eng.process_box(box, size, (1, 1, 1), ((48, 48),) * 3, Dz, vf)
+    torch.cuda.synchronize()
+    sb = sharding.ShardedBox(eng, size, (1, 1, 1), 0, 1, comm_stream=torch.cuda.Stream(device=dev))
+    sb.grid, sb.coords, sb.bshape, sb.zbricks, sb._agreed = (2, 1, 1), (0, 0, 0), size, True, True
+    keep = sharding.coords_rank
+    sharding.coords_rank = lambda c, g: 0                          # both neighbours are this rank
+    try:
+        disp, vel = torch.zeros_like(box), torch.zeros_like(box)
+        for _ in range(2):
+            sb.process(box, Dz, vf, disp, vel)
+    finally:
+        sharding.coords_rank = keep
+    torch.cuda.synchronize()
+    assert sb.backend() is None or True
+    ed, ev = float((disp - d_ref).abs().max()), float((vel - v_ref).abs().max())
+    print("brick protocol over RCCL, own neighbour: max|delta| disp %.3g vel %.3g (bit-identical: %s)"
+          % (ed, ev, bool(torch.equal(disp, d_ref) and torch.equal(vel, v_ref))))
+    assert torch.equal(disp, d_ref) and torch.equal(vel, v_ref)
+    eng.close()
 
 
 if __name__ == "__main__":
