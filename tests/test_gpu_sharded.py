@@ -154,3 +154,21 @@ def test_brick_calls_guard_their_state(engine_factory):
             e.check_finite()
     finally:
         e.set_input_range(None)
+
+
+def test_brick_protocol_over_rccl_with_one_rank_as_its_own_neighbour():
+    """RCCL refuses several ranks per device, so what can run on the nccl backend here is ONE rank: the process group, the
+    4-byte all-reduces, the grouped P2P of the exchanges to itself, and the whole brick step of ShardedBox -- four face exchanges
+    on the communication stream, events into the engine's stream -- with this rank as both of its z neighbours; a brick that is
+    its own neighbour is the periodic box, so the fields must equal process_box bit for bit (tools/gpu/rccl_self_check.py, in a
+    process of its own: the nccl process group must not meet the gloo groups of the other tests)."""
+    import subprocess
+    import sys
+    import jax_nbody_emulator_with_dj_amd as J
+    J.models.release_engines()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu", "rccl_self_check.py")], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and "rccl self check: ok" in r.stdout and "bit-identical: True" in r.stdout
