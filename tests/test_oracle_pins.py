@@ -241,3 +241,45 @@ def test_style_tangent_weight_factorises():
         xg = dx + alpha[:, None, None, None] * x
         rhs = np.einsum("oizyx,izyx->o", w_n, xg) + beta * np.einsum("oizyx,izyx->o", w_n, x)
         assert np.max(np.abs(lhs - rhs)) <= 1e-12 * np.max(np.abs(lhs))
+
+
+def test_torch_backend_and_branch_hook_of_the_oracle():
+    """The oracle's second evaluator of the stride-1 convolutions (torch-CPU conv3d, used for the production-width fixtures,
+    the kink-aware GPU checks and bench.py's cpu_baseline) is the NumPy tap-wise GEMM to float64 rounding; and the branch
+    hook of tests/kink.py: handing back the oracle's own branches changes nothing, flipping one branch changes the velocity
+    behind it and never the displacement (the primal follows the reference: layers_vel.py:184-185)."""
+    from oracle import layers as L, model as M, params as P
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((16, 7, 9, 8))
+    w = rng.standard_normal((8, 16, 3, 3, 3))
+    with L.backend('torch'):
+        yt = L.conv3(x, w)
+        y1 = L.conv1(x, w[:, :, :1, :1, :1])
+    np.testing.assert_allclose(yt, L.conv3(x, w), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(y1, L.conv1(x, w[:, :, :1, :1, :1]), rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        with L.backend('jax'):
+            pass
+    p = P.synthetic_params(seed=3, mid_chan=8)
+    xin = rng.standard_normal((3, 104, 104, 104)).astype(np.float32)
+    Om, Dz, vf = 0.3, 0.7731811501855036, 50.537651303131064
+    d0, v0 = M.forward_single(p, xin, Om, Dz, vf, False, True)
+    with L.backend('torch'):
+        d1, v1 = M.forward_single(p, xin, Om, Dz, vf, False, True)
+    assert np.abs(d1 - d0).max() <= 1e-12 and np.abs(v1 - v0).max() <= 1e-10
+    seen = []
+    d2, v2 = M.forward_single(p, xin, Om, Dz, vf, False, True, branch_hook=lambda name, pre: seen.append(name) or (pre > 0))
+    assert np.array_equal(d2, d0) and np.array_equal(v2, v0)
+    assert len(seen) == 23 and seen[0] == 'conv_l00/conv_0' and seen[-1] == 'conv_r01/conv_0' and 'conv_r01/conv_1' not in seen
+
+    def flip(name, pre):
+        b = pre > 0
+        if name == 'conv_r01/conv_0':
+            b = b.copy()
+            b[3, 5, 5, 5] = ~b[3, 5, 5, 5]
+        return b
+    d3, v3 = M.forward_single(p, xin, Om, Dz, vf, False, True, branch_hook=flip)
+    assert np.array_equal(d3, d0)
+    changed = np.argwhere(np.abs(v3 - v0).sum(axis=0) > 0)
+    # conv_r01/conv_0's voxel (5,5,5) feeds the 3^3 outputs around (4,4,4) of the 8^3 block (one VALID convolution later)
+    assert len(changed) > 0 and changed.min() >= 3 and changed.max() <= 5
