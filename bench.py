@@ -15,9 +15,9 @@ strict float32 MFMA path is timed on the same box and reported under "strict_f32
 available), which changes neither the FLOPs nor the bytes.  Rank 0 prints ONE JSON line.
 
 N > 1: the box is sharded as bricks over the ranks (jax_nbody_emulator_with_dj_amd/sharding.py) -- z-slabs whenever a
-slab is at least 44 planes deep: per step each rank exchanges 48 planes of raw input and 22 planes of down_l0 output
-with its two z neighbours over RCCL P2P and otherwise works alone (no halo recompute below the full-resolution level);
-total work is fixed (strong scaling).
+slab is at least 48 planes deep: per step each rank exchanges with its two z neighbours 4 planes of raw input, 6 planes of
+down_l0 output, 10 planes of down_l1 output and 4 planes of the level-0 skip connection over RCCL P2P (the two larger
+transfers under compute, on a second stream) and otherwise works alone; total work is fixed (strong scaling).
 """
 
 import argparse

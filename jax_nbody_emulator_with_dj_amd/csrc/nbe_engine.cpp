@@ -162,11 +162,11 @@ struct nbe_ctx {
     bool pyx = false;                             // current tile runs in periodic-yx mode (it spans the periodic box in y and x)
     bool pyx_allowed = true;                      // env NBE_PERIODIC=0 turns the mode off
     bool pz = false;                              // ... and the tile also spans the box in z (only with pyx)
-    // Brick mode of the sharded box (nbe_brick_encode / nbe_brick_finish): the tile is one rank's z-slab of the periodic
-    // box, periodic in y and x; in z it runs like pz, except that the 22 planes of level-1 context on either side are
-    // the neighbours' down_l0 outputs, exchanged between the two calls, instead of periodic wrap-around.
+    // Brick mode of the sharded box (nbe_brick_encode / _interior / _exchange / _finish): the tile is one rank's z-slab of
+    // the periodic box, periodic in y and x; in z it runs like pz, except that what the levels read beyond the brick's own
+    // planes comes from the neighbours (four exchanges between the calls, network_stream) instead of periodic wrap-around.
     bool zx = false;
-    int phase = 0;                                // 0: whole schedule; 1: up to the exchange; 2: from the exchange on
+    int phase = 0;                                // 0: whole schedule; 1 .. 4: the four brick calls (network_stream)
     struct BrickIO { void *send_lo = nullptr, *send_hi = nullptr; const void *recv_lo = nullptr, *recv_hi = nullptr;
                      void *skip_send_lo = nullptr, *skip_send_hi = nullptr; const void *skip_recv_lo = nullptr, *skip_recv_hi = nullptr;
                      hipEvent_t skip_ready = nullptr; } bio;

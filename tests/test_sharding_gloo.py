@@ -22,7 +22,7 @@ def test_rank_grid_and_bricks():
     # z-slab bricks that exchange their level-1 context (sharding.py): slabs of >= 44 planes beat cubes
     assert S.rank_grid(8, (4, 4, 4)) == (8, 1, 1) and S.rank_grid(8, (4, 4, 4), zbricks=False) == (2, 2, 2)
     assert S.rank_grid(8, (8, 8, 8)) == (8, 1, 1) and S.rank_grid(8, (8, 8, 8), zbricks=False) == (2, 2, 2)
-    assert S.rank_grid(8, (4, 4, 4), (256,) * 3) == (2, 2, 2)          # 32-plane slabs are too thin to hand out 22 planes twice
+    assert S.rank_grid(8, (4, 4, 4), (256,) * 3) == (2, 2, 2)          # 32-plane slabs are too thin for brick mode (a brick hands a quarter of its depth, 10 planes, to either neighbour)
     assert S._zbrick_factor(64) < 1.3 < S._halo_factor(256) ** 3
     assert S.rank_grid(16, (4, 4, 4)) == (4, 2, 2)
     assert S.rank_grid(2, (1, 4, 4), zbricks=False) == (1, 2, 1) and S.rank_grid(2, (1, 4, 4)) == (2, 1, 1)
@@ -133,7 +133,7 @@ def _zface_worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_z_face_exchange(world):
-    """The brick mode's one exchange per box: every rank's boundary planes land in the right neighbour's halo, also when
+    """A face exchange of the brick mode: every rank's boundary planes land in the right neighbour's halo, also when
     both neighbours are the same rank (world 2).  World 1 is a local periodic copy."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
