@@ -186,11 +186,23 @@ def main():
         eng.debug_phase_cycles()                  # timing-probe builds: reset the in-kernel phase counters
         eng.profile_reset()
         eng.profile_enable(not args.no_profile)
+        if sb is not None:
+            sb.wait_ms(); sb.trace = True          # how long the compute stream stands still for the face exchanges
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         fence()
         dt = time.perf_counter() - t0
+        if sb is not None:
+            sb.trace = False
+            w = sb.wait_ms()
+            wt = torch.tensor([w.get("down_l0 faces", 0.0), w.get("down_l1 faces", 0.0)], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+            graph_info["exchange_wait_ms_per_step"] = {"down_l0 faces (6 planes, under the interior of conv_l1)": float(wt[0]) / steps,
+                                                       "down_l1 faces (10 planes)": float(wt[1]) / steps,
+                                                       "note": "max over ranks of the time the compute stream stood still; the skip-connection "
+                                                               "planes are waited for inside nbe_brick_finish, after levels 1-3"}
         eng.profile_enable(False)
         prof = [] if args.no_profile else eng.profile_read()
         replays = eng.query("graph_replays")
@@ -258,6 +270,7 @@ def main():
 
     dt, prof, ok, plan = measure(args.precision, args.warmup, args.steps)
     main_replays = graph_info.get("replays")
+    main_waits = graph_info.get("exchange_wait_ms_per_step")
 
     def measure_host_path(steps):
         """The reference's call shape (subbox.py:139-219): host NumPy array in, host NumPy arrays out, through the public
@@ -353,7 +366,8 @@ def main():
                            "%s (host-staged: the one-card test rig, not a multi-GPU measurement)" % sb.backend()),
                        "internal_tiles": plan, "precision": args.precision,
                        "traffic_key": traffic_key(args.precision, plan),
-                       "tiles_replayed_from_hipgraphs": main_replays},
+                       "tiles_replayed_from_hipgraphs": main_replays,
+                       "exchange_wait_ms_per_step": main_waits},
             "finite": ok,
         }
         if prof:

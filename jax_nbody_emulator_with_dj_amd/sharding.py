@@ -233,6 +233,8 @@ class ShardedBox:
         self._halo = None                       # (send_lo, send_hi, recv_lo, recv_hi), allocated once
         self.fallback = None                    # optional strict-float32 Engine with the same parameters (see process)
         self._agreed = False                    # the ranks have agreed on brick mode vs padded bricks (first call)
+        self.trace = False                      # bracket the compute stream's waits for exchanges with timing events (wait_ms)
+        self._waits = []
 
     def _exchange_async(self, cur, send_lo, send_hi, recv_lo, recv_hi):
         """Face exchange on the communication stream, behind what `cur` has enqueued so far; returns the event the consumer
@@ -263,16 +265,37 @@ class ShardedBox:
         self.eng.brick_encode(H, self.bshape, Dz, vel_fac, s_lo, s_hi, k_lo, k_hi)
         ev = self._exchange_async(cur, s_lo, s_hi, r_lo, r_hi)
         self.eng.brick_interior()                                   # runs while the faces travel
-        if ev is not None:
-            cur.wait_event(ev)
+        self._wait(cur, ev, "down_l0 faces")
         self.eng.brick_exchange(r_lo, r_hi, s2_lo, s2_hi)
         ev = self._exchange_async(cur, s2_lo, s2_hi, r2_lo, r2_hi)
         # the skip connection's planes go last on the communication stream (behind the faces the compute stream is waiting
         # for) and are needed last: the engine waits for them after levels 1-3, inside brick_finish
         ev_skip = self._exchange_async(cur, k_lo, k_hi, q_lo, q_hi)
-        if ev is not None:
-            cur.wait_event(ev)
+        self._wait(cur, ev, "down_l1 faces")
         self.eng.brick_finish(r2_lo, r2_hi, q_lo, q_hi, Dz, vel_fac, disp, vel, skip_ready=ev_skip)
+
+    def _wait(self, cur, ev, what):
+        """The compute stream waits for an exchange.  With self.trace the wait is bracketed by timing events: how long the
+        stream actually stood still for it is the gap between them (read by wait_ms() after the step)."""
+        if ev is None:
+            return
+        if self.trace and cur is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(cur)
+            cur.wait_event(ev)
+            b.record(cur)
+            self._waits.append((what, a, b))
+        else:
+            cur.wait_event(ev)
+
+    def wait_ms(self):
+        """{exchange: ms the compute stream stood still for it}, summed over the steps since the last call (trace=True)."""
+        out = {}
+        for what, a, b in self._waits:
+            b.synchronize()
+            out[what] = out.get(what, 0.0) + a.elapsed_time(b)
+        self._waits = []
+        return out
 
     def _agree_on_bricks(self, device):
         """A brick whose workspace does not fit the memory that is free now runs as padded bricks instead; every rank must

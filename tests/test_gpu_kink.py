@@ -171,6 +171,21 @@ def test_subbox_224_matches_float64_fixture_and_cone_oracle(engine_factory, prec
     ev = np.abs(np.concatenate([(v[:, ::4, ::4, ::4] - gold["t224_vel_s4"]).ravel(), (v[:, 56:72, 56:72, 56:72] - gold["t224_vel_c16"]).ravel()])) / rms_v
     print("224^3 sub-box %s vel against the fixture's own branches: median %.2e, %.2f %% beyond 2e-4 RMS, max %.2e" % (prec, np.median(ev), 100 * (ev > 2e-4).mean(), ev.max()))
     assert np.median(ev) <= 5e-6
+    # the displacement-only twin (style_nbody_emulator_core.py:101-175; f16x3: conv_h3w_kernel<., NOVEL> with fused skips) against
+    # the same fixture: vel primal == non-vel (tests/test_style_nbody_emulator_vel_core.py), at the reference's sub-box shape
+    en = engine_factory(mid_chan=mid, compute_vel=False, precision=prec)
+    en.load_params(p, premodulated=False)
+    en.set_cosmology(OM, DZ)
+    en.profile_enable(True)
+    dn = en.forward(x, DZ)
+    en.profile_enable(False)
+    if prec == "f16x3":
+        assert any(k["kernel"].startswith("conv_h3w<FLAT3,novel>") for k in en.profile_read())
+    for name, got in (("s4", dn[:, ::4, ::4, ::4]), ("c16", dn[:, 56:72, 56:72, 56:72])):
+        want = gold["t224_disp_" + name]
+        ed = rel_l2(got, want), float(np.abs(got - want).max() / rms_d)
+        print("224^3 sub-box %s displacement-only %s: %.2e / %.2e" % (prec, name, *ed))
+        assert ed[0] <= 2e-5 and ed[1] <= 2e-4, (name, ed)
     if prec == "f16x3":         # (strict float32 takes the same schedule through the same probe: config 1 covers it causally)
         d_o, v_o, st = kink.oracle_cone(p, kink.cone_input_valid(x, o, 8), OM, DZ, VF, br)
         kink.assert_cone("224^3 sub-box %s block %s" % (prec, o), _block(d, o, 8), _block(v, o, 8), d_o, v_o, st, rms_d=rms_d, rms_v=rms_v)
