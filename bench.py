@@ -261,7 +261,8 @@ def main():
                     traffic = sum(v["traffic_bytes"] * v["launches"] for v in m) / sum(v["launches"] for v in m)
         except Exception:
             traffic = None
-        mpp = {"f32": 1.0, "f16x3": 3.0, "f16": 1.0}[precision] * (2.0 / 3.0 if dom["kernel"].startswith("conv_h3w") else 1.0)
+        wino = dom["kernel"].startswith("conv_h3w") or dom["kernel"].startswith("conv_h1w")   # (conv_h1w: the float16 model's form)
+        mpp = {"f32": 1.0, "f16x3": 3.0, "f16": 1.0}[precision] * (2.0 / 3.0 if wino else 1.0)
         full = {"f32": PEAK_F32_MFMA_TFLOPS}.get(precision, PEAK_F16_MFMA_TFLOPS)
         return {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": traffic, "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),

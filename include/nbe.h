@@ -248,6 +248,12 @@ int nbe_test_layer(nbe_ctx* ctx, int kind, int crop, int flags, const float* x, 
  * and NBE_WINO is not 0, else conv_h3g_kernel. */
 int nbe_test_layer_gauged(nbe_ctx* ctx, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
                           const float* w, const float* beta, const float* bias, int cout, float* y, float* dy);
+/* The same with flags bit 2: res / dres (shaped like the output) are added before the activation -- the float16 model's
+ * conv_1 launches, whose Winograd-z form (conv_h3w_kernel<., ., F16>; Cin a multiple of 32) adds the block's skip there.
+ * Other precisions run their direct gauged kernels when the residual flag is set. */
+int nbe_test_layer_gauged_res(nbe_ctx* ctx, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
+                              const float* w, const float* beta, const float* bias, int cout, const float* res,
+                              const float* dres, float* y, float* dy);
 /* modulation kernel alone: OIDHW weight -> (w_n, dw_tot) */
 int nbe_test_modulate(nbe_ctx* ctx, const float* weight, const float* style_weight, const float* style_bias,
                       int cout, int cin, int k, float s0, float s1, float eps, int first_layer,

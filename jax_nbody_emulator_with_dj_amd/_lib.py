@@ -82,6 +82,9 @@ SIGNATURES = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nbe_test_layer_gauged": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "nbe_test_layer_gauged_res": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "nbe_test_modulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "nbe_probe_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -504,6 +504,8 @@ static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 =
     return b;
 }
 
+// the float16 model's Winograd-z form (conv_h3w_kernel<., ., F16>): 32-channel stages
+static bool wino_f16_layer(int prec, bool vel, int cin_pad) { return prec == PREC_F16 && vel && cin_pad % 32 == 0 && cin_pad / 32 <= 8; }
 static bool wino_env_off() { return getenv("NBE_WINO") && atoi(getenv("NBE_WINO")) == 0; }   // A/B switch, read per launch
 static bool narrow_off() { return getenv("NBE_NARROW") && atoi(getenv("NBE_NARROW")) == 0; }   // A/B switch (set before the context is created)
 static bool narrow_tile(const Layer* L) { return L->pwn.w && !narrow_off(); }
@@ -525,11 +527,13 @@ static int run_conv(nbe_ctx* c, const Layer& L, const ConvLaunch& cl_in, bool ha
     const PackedW& pw = (g6 && L.kind == 0 && narrow_tile(&L)) ? L.pwn : L.pw;
     // Winograd along z (conv_h3w_kernel): gauged wide 3x3x3 launches without a fused skip or residual, on an even number
     // of output planes (the conditions of launch_h3w).  NBE_WINO=0 is the A/B switch (read per launch: tests flip it).
-    cl.wino = (g6 || nov) && c->wino_ok && &pw == &L.pw && pw.ww && (!cl.skw || cl.skw->ww) && !(cl.flags & F_RES) && (cl.Dv & 1) == 0 && cl.in_off == 0 &&
-              cl.osz == 1 && !wino_env_off();
+    // (the float16 model's form adds the residual in its epilogue: its blocks run their skips as launches of their own)
+    cl.wino = (g6 || nov) && c->wino_ok && &pw == &L.pw && pw.ww && (!cl.skw || cl.skw->ww) && (c->prec == PREC_F16 || !(cl.flags & F_RES)) &&
+              (cl.Dv & 1) == 0 && cl.in_off == 0 && cl.osz == 1 && !wino_env_off();
     int pe = -1; hipEvent_t ea = nullptr, eb = nullptr;
     if (c->prof) {
-        std::string pn = cl.wino ? std::string(c->vel ? "conv_h3w<FLAT3,vel,dx>" : "conv_h3w<FLAT3,novel>") : conv_name(pw, c->vel, has_dx, g6, cl.set < 0);
+        std::string pn = cl.wino ? std::string(c->prec == PREC_F16 ? "conv_h1w<FLAT3,vel,dx>" : c->vel ? "conv_h3w<FLAT3,vel,dx>" : "conv_h3w<FLAT3,novel>")
+                                 : conv_name(pw, c->vel, has_dx, g6, cl.set < 0);
         static const bool per_layer = getenv("NBE_PROF_LAYERS") && atoi(getenv("NBE_PROF_LAYERS")) == 1;   // tools: one entry per layer
         if (per_layer) pn += " " + L.block + "/" + L.layer;
         pe = prof_entry(c, pn);
@@ -1528,12 +1532,12 @@ static const char* kBlocks[15] = {"conv_l00", "conv_l01", "down_l0", "conv_l1", 
 // Winograd-z weights of the gauged wide 3x3x3 layers (conv_h3w_kernel), from the modulated weights L.wn that are current
 static int pack_wino(nbe_ctx* c) {
     c->wino_ok = false;
-    if (!(c->prec == PREC_F16X3 && (c->vel ? c->gauge_active : true))) return 0;
+    if (!((c->prec == PREC_F16X3 && (c->vel ? c->gauge_active : true)) || (c->prec == PREC_F16 && c->vel && c->gauge_active))) return 0;
     if (!c->wino_flag) HIPCHK(hipMalloc((void**)&c->wino_flag, 4));
     HIPCHK(hipMemsetAsync(c->wino_flag, 0, 4, c->stream));
     for (auto& kv : c->layers) {
         Layer& L = kv.second;
-        if (L.pw.ww && L.kind == 0 && (L.g6 || !c->vel)) launch_pack_h3w(L.wn, L.cout, L.cin, L.pw.cin_pad, L.pw.ctiles, L.pw.ww, c->wino_flag, c->stream);
+        if (L.pw.ww && L.kind == 0 && (L.g6 || !c->vel)) launch_pack_h3w(L.wn, L.cout, L.cin, L.pw.cin_pad, L.pw.ctiles, L.pw.ww, c->wino_flag, c->stream, c->prec);
         if (L.pw.ww && L.kind == 1 && (c->vel ? (L.b_sub && c->fuse) : c->novel_fuse)) {   // a fused skip: [W_s | dW_s~] for conv_h3w_kernel<SKIP>
             launch_pack_h3w_skip(L.wn, L.cout, L.cin, L.pw, L.pw.ww, c->wino_flag, c->stream);
             if (c->vel) launch_pack_h3w_skip(L.dwn, L.cout, L.cin, L.pw, L.pw.ww + L.pw.floats, c->wino_flag, c->stream);
@@ -1775,7 +1779,8 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             if (L.kind == 1) HIPCHK(hipMalloc((void**)&pn.dw, pn.floats * 4));   // a skip that runs inside the narrow conv_1
         }
         // Winograd-z packing (conv_h3w_kernel): 4 transformed kernels per 3 dz slices, wide tile only, Cin <= 128
-        if (c->prec == PREC_F16X3 && L.kind == 0 && !L.first && !L.pwn.w && pw.cin_pad / 16 <= 8)
+        if ((c->prec == PREC_F16X3 && L.kind == 0 && !L.first && !L.pwn.w && pw.cin_pad / 16 <= 8) ||
+            (L.kind == 0 && !L.first && wino_f16_layer(c->prec, c->vel, pw.cin_pad)))
             HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
         if (c->prec == PREC_F16X3 && L.kind == 1 && !L.pwn.w && pw.cin_pad / 16 <= 8)     // a skip that may run fused: W_s and dW_s~
             HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 2 * 4));
@@ -2802,11 +2807,11 @@ static int test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x,
             TCHK(hipMalloc((void**)&L.beta, nbt * 4)); TCHK(hipMemset(L.beta, 0, nbt * 4));
             TCHK(hipMemcpy(L.beta, beta, cout * 4, hipMemcpyHostToDevice));
             L.g6 = true; c->gauge_active = true; c->wino_ok = false;
-            if (c->prec == PREC_F16X3 && pw.cin_pad / 16 <= 8) {
+            if ((c->prec == PREC_F16X3 && pw.cin_pad / 16 <= 8) || wino_f16_layer(c->prec, true, pw.cin_pad)) {
                 TCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
                 if (!c->wino_flag) TCHK(hipMalloc((void**)&c->wino_flag, 4));
                 TCHK(hipMemsetAsync(c->wino_flag, 0, 4, c->stream));
-                launch_pack_h3w(dwt, cout, cin, pw.cin_pad, pw.ctiles, pw.ww, c->wino_flag, c->stream);
+                launch_pack_h3w(dwt, cout, cin, pw.cin_pad, pw.ctiles, pw.ww, c->wino_flag, c->stream, c->prec);
                 int bad = 0;
                 TCHK(hipMemcpyAsync(&bad, c->wino_flag, 4, hipMemcpyDeviceToHost, c->stream));
                 TCHK(hipStreamSynchronize(c->stream));
@@ -2907,6 +2912,13 @@ int nbe_test_layer_gauged(nbe_ctx* c, int flags, const float* x, const float* dx
                           const float* w, const float* beta, const float* bias, int cout, float* y, float* dy) {
     if (!beta) return fail("null argument");
     return test_layer(c, 0, 0, flags, x, dx, cin, D, H, W, w, nullptr, bias, cout, nullptr, nullptr, y, dy, beta);
+}
+
+int nbe_test_layer_gauged_res(nbe_ctx* c, int flags, const float* x, const float* dx, int cin, int D, int H, int W,
+                              const float* w, const float* beta, const float* bias, int cout, const float* res, const float* dres,
+                              float* y, float* dy) {
+    if (!beta) return fail("null argument");
+    return test_layer(c, 0, 0, flags, x, dx, cin, D, H, W, w, nullptr, bias, cout, res, dres, y, dy, beta);
 }
 
 int nbe_profile_enable(nbe_ctx* c, int on) { if (!c) return fail("null context"); prof_collect(c); c->prof = on != 0; return 0; }

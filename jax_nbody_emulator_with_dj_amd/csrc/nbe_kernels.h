@@ -105,7 +105,8 @@ void launch_pack(const float* w_oidhw, int cout, int cin, int kind, const Packed
 
 // Winograd-z packing of a 3x3x3 layer's modulated weights for conv_h3w_kernel (nbe_kernels_wino.h): dst holds 4/3 of
 // PackedW::floats; *flag |= 1 when a weight leaves the f16 range at the kernel's 2^14 scale
-void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int ctiles, float* dst, int* flag, hipStream_t s);
+void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int ctiles, float* dst, int* flag, hipStream_t s,
+                     int prec = PREC_F16X3);   // PREC_F16: the float16 model's form (32-channel stages, one part)
 // a fused skip's weights (FLAT1 packing of pw) in that kernel's scaling: dst holds pw.floats floats
 void launch_pack_h3w_skip(const float* w_oidhw, int cout, int cin, const PackedW& pw, float* dst, int* flag, hipStream_t s);
 

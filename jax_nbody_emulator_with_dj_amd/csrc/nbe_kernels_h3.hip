@@ -2190,6 +2190,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
             if (ka.ww && launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s) == 0) return 0;     // Winograd along z; 1: no such form for this launch
             return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
         }
+        if (ka.ww && launch_h3w(ka, ka.ww, nullptr, 0, ct, s, false, true) == 0) return 0;   // float16 model: Winograd along z
         return launch_h2q<false, true>(ka, ct, s);
     }
     const bool first_flat = l0_flat && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.nchunk == 1;

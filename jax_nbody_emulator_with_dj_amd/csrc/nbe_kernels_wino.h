@@ -35,6 +35,7 @@
 constexpr int NBE_MAX_WSTAGES = 32;                // 4 * Cin / 16: Cin <= 128
 constexpr int NBE_MAX_WSKIP = 16;                  // fused skip: 2 planes x Cin_block / 16 raw stages after the transformed ones
 constexpr float WINO_WSCALE = 16384.0f;            // 2^14
+constexpr float WINO_WSCALE_F16 = 256.0f;          // the float16 form: no lo part to keep out of the subnormals, 2^8 for the small weights
 
 struct WinoSrc { const char* xa; const char* xb; long dxd; const char* w; long psb; float sb; int pad_; };
 
@@ -44,6 +45,7 @@ struct WinoKArgs {
     int zblock;                // tile order: plane pairs fastest in blocks of this many (>= 1)
     float* y; float* dy; long out_pstride; int out_g0;
     const float* bias; const float* gout; const float* beta;
+    const float* r; const float* dr; long res_pstride;          // F16 with F_RES: the residual (geometry of the output)
     float inv_scale;
     int nskip;                 // SKIP: 16-channel chunks of the block input (two raw stages each, plane z0 and plane z0 + 1)
     long dws_delta;            // SKIP: bytes from the scaled W_s to the scaled dW_s~ of a chunk
@@ -63,8 +65,17 @@ struct WinoKArgs {
 // which is what the one-accumulator-set form lacks (conv_h2q_kernel<SPLIT> doubles its tile for the same reason).  Only
 // the epilogue (bias and LeakyReLU for both sets, both stored to y) and the fused skip's products (W_s.x for both row
 // blocks, no dW_s~) differ.
-template <bool SKIP, bool NOVEL>
+//
+// F16: the plain-float16 model (NBE_PREC_F16: one f16 plane per eight channels, one MFMA per product) on the same LDS image
+// and stage skeleton.  What is the (hi, lo) pair of a 16-channel chunk above is here a pair of 16-channel chunks: a stage
+// covers 32 input channels (plane u = 2 h + part of the stage <-> channels 8 u .. 8 u + 7), the transform is V = a +- b on
+// each plane by itself (one packed operation per register), a tap pair runs four products (w0.x0 + w1.x1 into Y, w0.dx0~ +
+// w1.dx1~ into DY) and the single tap one product per set with K = [part 0 | part 1] fully used: 144 MFMAs per stage and wave,
+// none wasted.  Weights are scaled by 2^8 only (no lo part to protect).  The epilogue adds the residual (F_RES: the block's
+// skip as computed by its own launch -- the float16 model has no fused skip), rounds once and stores one plane per unit.
+template <bool SKIP, bool NOVEL, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
+    static_assert(!(F16 && (NOVEL || SKIP)), "the float16 form has neither a fused skip nor a displacement-only variant");
     typedef HGGeom<false, true, false> G;
     constexpr int NW = 8, CT = 64, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = 4, NT = 2, NTILE = 8;
     f32x4* lds = lds_h3;
@@ -215,6 +226,12 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         const unsigned AH = __builtin_bit_cast(u32x4, g.ah)[r], AL = __builtin_bit_cast(u32x4, g.al)[r];
         const unsigned BH = __builtin_bit_cast(u32x4, g.bh)[r], BL = __builtin_bit_cast(u32x4, g.bl)[r];
         const unsigned sbp = g.sb < 0.f ? 0xBC00BC00u : 0x3C003C00u, k2048 = 0x68006800u;      // packed (sb, sb), (2048, 2048)
+        if (F16) {                                               // two independent planes: V = a + sb b, one rounding each
+            if (m == 0) asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(x.s) : "v"(BH), "s"(sbp), "v"(AH));
+            else if (m == 1) asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(x.l1) : "v"(BL), "s"(sbp), "v"(AL));
+            else if (m == 3) { x.HI[r] = x.s; x.LO[r] = x.l1; }
+            (void)k2048;
+        } else
         if (m == 0) {
             asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(x.s) : "v"(BH), "s"(sbp), "v"(AH));
             asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x.bb) : "v"(x.s), "v"(AH));
@@ -319,6 +336,21 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // (mid: after the third product every LDS read of the pair has been issued -- the stage's barrier goes there)
     auto pair = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int slot0, int nb, bool px, int wa, int xp,
                     auto&& preXl, auto&& preW, auto&& preXh, auto&& mid, bool hooked, auto&& hook, auto&& after3) {
+        if (F16) {
+            // four products: w0.x0 + w1.x1 -> Y, w0.dx0~ + w1.dx1~ -> DY (wh / wl: the weights of the stage's two 16-channel
+            // halves, xh / xl and dxh / dxl their planes); every LDS read of the pair is issued before the second product
+            LB(dxh, xp + HQ_XT); LA(wl, wa + CT + aP);
+            NBE_SB; MM8h(Y, wh, xh, slot0, nb, px, false, hooked, [&](int t) { hook(t); }); NBE_SB;
+            LB(dxl, xp + HQ_XT + HQ_PP);
+            NBE_SB; MM8h(Y, wl, xl, slot0 < 0 ? -1 : slot0 + 2, nb, px, false, hooked, [&](int t) { hook(8 + t); }); NBE_SB;
+            after3();
+            mid();
+            preXl(); preXh();
+            NBE_SB; MM8(DY, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px); NBE_SB;
+            preW();
+            NBE_SB; MM8(DY, wl, dxl, -1, nb, px); NBE_SB;
+            return;
+        }
         LB(dxh, xp + HQ_XT);
         NBE_SB; MM8s(Y, wp, wh, xl, slot0, nb, px); NBE_SB;                               // hi(w) 2^-11 . lo(x)
         LB(dxl, xp + HQ_XT + HQ_PP);
@@ -365,12 +397,17 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
              none, false, nohook, none);
         half8 a1[MT], a2[MT], b1x[NT], b1d[NT];
         // single tap 4 = (dy 1, dx 1): the K halves select the PART: [wh | wh 2^-11] . [xh | xl] and [wl | 0] . [xh | xl]
-        const int aS = wb + 4 * TAPU + (2 * kh) * CT + c;
+        const int aS = wb + 4 * TAPU + (2 * kh + (F16 ? ks : 0)) * CT + c;
         const int bS = xb + (2 * kh + ks) * HQ_PP + rowp * HP_RS + c + SH4;
         pair(Y, DY, -1, nb, px, wb + 2 * TAPU, xb + 2 + bP32,                             // taps (2,3)
              [&] { LB(b1x, bS); }, [&] { LA(a1, aS); }, [&] { LB(b1d, bS + HQ_XT); }, none,
              px, hk, [&] { if (px) { st_write(0, nb, xf); st_load(1, g); } });
         const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (F16) {                                               // [w0 | w1] . [x0 | x1]: one product per set, K fully used
+            NBE_SB; MM8(Y, a1, b1x, -1, 0, false); NBE_SB;
+            LB(xl, xb + SH5 + bP32 + HQ_PP); LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
+            NBE_SB; MM8(DY, a1, b1d, -1, 0, false); NBE_SB;
+        } else {
         {
             const _Float16 m1 = ks ? kInv : (_Float16)1.0f;
 #pragma unroll
@@ -387,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         // rather than 6 / 8 / 4, was measured: +-0: the loads' latency is not exposed)
         NBE_SB; MM8(Y, a2, b1x, -1, 0, false, true); NBE_SB;
         MM8(DY, a2, b1d, -1, 0, false); NBE_SB;
+        }
         pair(Y, DY, -1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                           // taps (5,6)
              [&] { LB(xl, xb + SH7 + bP1 + HQ_PP); }, [&] { LA(wh, wb + 7 * TAPU + aP); }, [&] { LB(xh, xb + SH7 + bP1); },
              none, px, hk, [&] { if (px) { st_write(1, nb, xf); st_load(2, g); } });
@@ -528,6 +566,21 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             ook2[nt] = NOVEL && yy + HP_ROWS < a.Hv && xx < a.Wv;
             o[nt] = ook[nt] ? (z * a.Ho + yy) * a.Wo + xx : z * a.Ho * a.Wo;
         }
+        // F16 with a residual: the plane's sixteen residual vectors are loaded before anything of the plane is stored (vmcnt
+        // counts loads and stores alike, see above)
+        half4 r0[F16 ? NTILE : 1], r1[F16 ? NTILE : 1];
+        const bool res = F16 && (a.flags & F_RES);
+        if (F16 && res) {
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+                const int mt = t / NT, nt = t % NT;
+                const long rb = ((long)unit[mt] * a.res_pstride + (long)o[nt]) * 16 + 8 * kh;
+                r0[t] = *(const half4*)((const char*)a.r + rb);
+                r1[t] = *(const half4*)((const char*)a.dr + rb);
+            }
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) asm volatile("" : "+v"(r0[t]), "+v"(r1[t]));
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -541,6 +594,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
                     v[e] = yp + bv[mt][e];
                     dv[e] = acc_read(DY[t][e]) * a.inv_scale + be[mt][e] * yp;
                 }
+                if (F16 && res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += (float)r0[t][e]; dv[e] += (float)r1[t][e]; }
+                }
                 if (act) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -552,6 +609,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dv[e] += gv[mt][e] * v[e];
                 }
+                if (F16) {                                       // one f16 plane per unit; the residual was added before the activation
+                    if (uok[mt] && ook[nt]) {
+                        const long ob = ((long)(a.out_g0 + unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
+                        half4 h, dh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { h[e] = (_Float16)v[e]; dh[e] = (_Float16)dv[e]; }
+                        *(half4*)((char*)a.y + ob) = h;
+                        *(half4*)((char*)a.dy + ob) = dh;
+                    }
+                } else
                 if (NOVEL) {                                     // two row blocks of y: bias and LeakyReLU on both sets
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -595,8 +662,10 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 // [ct][stage = chunk*4 + xi][tap = 3*dy + dx][u = 2*h + part][co 64][j 8], channel = chunk*16 + 8*h + j;
 // value = U_xi[oc, ci, dy, dx] * 2^14 (U3 negated), part 0 = its f16 rounding, part 1 = the remainder, unscaled.
 // *flag |= 1 when a scaled weight leaves the f16 range (the layer then stays on the direct kernel).
+// f16 (the float16 model, conv_h3w_kernel<., ., true>): a stage is 32 channels, channel = chunk*32 + 8*u + j, every u holds
+// the f16 rounding of U_xi * 2^8.
 __global__ __launch_bounds__(256) void pack_h3w_kernel(const float* __restrict__ w, int cout, int cin, int nchunk, long total,
-                                                       _Float16* __restrict__ dst, int* __restrict__ flag) {
+                                                       _Float16* __restrict__ dst, int* __restrict__ flag, int f16) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     long r = idx;
@@ -608,34 +677,41 @@ __global__ __launch_bounds__(256) void pack_h3w_kernel(const float* __restrict__
     const int ct = (int)r;
     const int chunk = stage >> 2, xi = stage & 3;
     const int h = u >> 1, part = u & 1;
-    const int ci = chunk * 16 + 8 * h + j, oc = ct * 64 + co;
+    const int ci = f16 ? chunk * 32 + 8 * u + j : chunk * 16 + 8 * h + j, oc = ct * 64 + co;
     float v = 0.f;
     if (oc < cout && ci < cin) {
         const float* p = w + (((size_t)oc * cin + ci) * 3) * 9 + tap;        // [dz][dy][dx]
         const float w0 = p[0], w1 = p[9], w2 = p[18];
         v = xi == 0 ? w0 : xi == 1 ? 0.5f * (w0 + w1 + w2) : xi == 2 ? 0.5f * (w0 - w1 + w2) : -w2;
     }
-    v *= WINO_WSCALE;
+    v *= f16 ? WINO_WSCALE_F16 : WINO_WSCALE;
     if (!(fabsf(v) <= 60000.f)) { atomicOr(flag, 1); v = 0.f; }
     const _Float16 hi = (_Float16)v;
-    dst[idx] = part == 0 ? hi : (_Float16)(v - (float)hi);
+    dst[idx] = (part == 0 || f16) ? hi : (_Float16)(v - (float)hi);
 }
 
-void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int ctiles, float* dst, int* flag, hipStream_t s) {
-    const int nchunk = cin_pad / 16;
+void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int ctiles, float* dst, int* flag, hipStream_t s, int prec) {
+    const bool f16 = prec == PREC_F16;
+    const int nchunk = cin_pad / (f16 ? 32 : 16);
     const long total = (long)ctiles * 4 * nchunk * 9 * 4 * 64 * 8;
     hipLaunchKernelGGL(pack_h3w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin, nchunk, total,
-                       (_Float16*)dst, flag);
+                       (_Float16*)dst, flag, f16 ? 1 : 0);
 }
 
 // 0: launched; 1: this launch has no Winograd form (the caller falls back to conv_h3g_kernel)
 // wws: the fused skip's weights [W_s | dW_s~] in the kernel's scaling (PackedW::ww of the skip layer), needed when ka.nskip > 0
 // novel: the displacement-only form (conv_h3w_kernel<SKIP, true>): no tangent tensors, two row blocks per workgroup
-static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, long wws_set_floats, int ctiles, hipStream_t s,
-                      bool novel = false) {
+// f16: the float16 model's form (32-channel stages, no fused skip, residual in the epilogue)
+static int launch_h3w(const ConvKArgs& ka_in, const float* ww, const float* wws, long wws_set_floats, int ctiles, hipStream_t s,
+                      bool novel = false, bool f16 = false) {
     typedef HGGeom<false, true, false> G;
     constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
-    if (!ww || (ka.flags & F_RES) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || (!novel && !ka.beta)) return 1;
+    ConvKArgs ka = ka_in;
+    if (f16) {                                                   // 16-channel chunks -> 32-channel stages
+        if (novel || ka.nskip > 0 || (ka.nchunk & 1) || (ka.csplit < ka.nchunk && (ka.csplit & 1))) return 1;
+        ka.nchunk /= 2; if (ka.csplit < (1 << 29)) ka.csplit /= 2;
+    }
+    if (!ww || (!f16 && (ka.flags & F_RES)) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || (!novel && !ka.beta)) return 1;
     if (ka.nskip > 0 && (!wws || 2 * ka.nskip > NBE_MAX_WSKIP)) return 1;
     if (ctiles != (ka.cout_groups + 7) / 8) return 1;
     // the raw planes are fetched with buffer loads (32-bit offsets): lane offset + hi -> lo plane distance stay below 2^32
@@ -646,6 +722,7 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     WinoKArgs wa;
@@ -658,7 +735,8 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
     wa.y = ka.y; wa.dy = ka.dy; wa.out_pstride = ka.out_pstride; wa.out_g0 = ka.out_g0;
     wa.bias = ka.bias; wa.gout = novel ? nullptr : ka.gout; wa.beta = novel ? nullptr : ka.beta;
     const long rows8 = (long)HP_ROWS * ka.W * 16;                // novel: the "tangent" patch is the input eight rows further down
-    wa.inv_scale = 1.0f / WINO_WSCALE;
+    wa.inv_scale = 1.0f / (f16 ? WINO_WSCALE_F16 : WINO_WSCALE);
+    wa.r = ka.r; wa.dr = ka.dr; wa.res_pstride = ka.res_pstride;
     {
         // A/B (profiles/r02_ab_wino_zblock.txt): 0 = all pairs of the launch (z fastest) 1494 ms per box, 1 (x fastest) 1496,
         // 2 / 4 / 8 / 16: 1479 / 1481 / 1477 / 1482
@@ -697,7 +775,8 @@ static int launch_h3w(const ConvKArgs& ka, const float* ww, const float* wws, lo
             e.xa = x + off; e.xb = e.xa; e.dxd = novel ? rows8 : dx - x; e.w = (const char*)wws + (long)sc * G::TAPU * 16; e.psb = ps * 16; e.sb = 0.f; e.pad_ = 0;
         }
     dim3 grid(wa.ntiles * ctiles, 1, 1), block(512, 1, 1);
-    if (novel) {
+    if (f16) hipLaunchKernelGGL((conv_h3w_kernel<false, false, true>), grid, block, smem, s, wa);
+    else if (novel) {
         wa.dws_delta = 0;
         if (ka.nskip > 0) hipLaunchKernelGGL((conv_h3w_kernel<true, true>), grid, block, smem, s, wa);
         else hipLaunchKernelGGL((conv_h3w_kernel<false, true>), grid, block, smem, s, wa);

@@ -369,13 +369,19 @@ class Engine:
                                      _ptr(bias), cout, _ptr(res), _ptr(dres), _ptr(y), _ptr(dy)))
         return (y, dy) if vel else y
 
-    def test_layer_gauged(self, x, dx, w, beta, bias, act=False):
-        """3x3x3 layer in the gauged form: y = W.x + b, dy = W.dx + beta[o] * (W.x) (nbe_test_layer_gauged)."""
+    def test_layer_gauged(self, x, dx, w, beta, bias, act=False, res=None, dres=None):
+        """3x3x3 layer in the gauged form: y = W.x + b, dy = W.dx + beta[o] * (W.x) (nbe_test_layer_gauged);
+        res / dres: a residual added before the activation (nbe_test_layer_gauged_res)."""
         x, dx, w, beta, bias = _f32(x), _f32(dx), _f32(w), _f32(beta), _f32(bias)
         cin, D, H, W = x.shape
         cout = w.shape[0]
         y = np.empty((cout, D - 2, H - 2, W - 2), np.float32)
         dy = np.empty_like(y)
+        if res is not None:
+            res, dres = _f32(res), _f32(dres)
+            check(self._l.nbe_test_layer_gauged_res(self._h, (1 if act else 0) | 2, _ptr(x), _ptr(dx), cin, D, H, W, _ptr(w),
+                                                    _ptr(beta), _ptr(bias), cout, _ptr(res), _ptr(dres), _ptr(y), _ptr(dy)))
+            return y, dy
         check(self._l.nbe_test_layer_gauged(self._h, 1 if act else 0, _ptr(x), _ptr(dx), cin, D, H, W, _ptr(w), _ptr(beta),
                                             _ptr(bias), cout, _ptr(y), _ptr(dy)))
         return y, dy

@@ -33,6 +33,29 @@ def _chk(got, want, what, half=False):
     assert e2 <= t2 and em <= tm, "%s: rel_l2=%.3e max/rms=%.3e" % (what, e2, em)
 
 
+# the float16 model's Winograd-z form: U_xi and V = a +- b are rounded to float16 once more (measured: 4.6e-4 / 3.9e-3;
+# the direct kernel on the same operands 2.1e-4)
+RTOL_L2_F16W = 7e-4
+RTOL_MAX_F16W = 7e-3
+
+
+def _chk_f16w(got, want, what, pre=None, dpre=None):
+    """pre / dpre: the oracle's pre-activation value and tangent.  The tangent of LeakyReLU jumps by a factor of 100 where
+    the value changes sign, and this form's value carries ~3e-4 of rounding before the activation: voxels whose oracle
+    pre-activation lies within 1e-2 RMS of zero may take either branch (each within the plain tolerance of that branch);
+    every other voxel meets the plain tolerances."""
+    assert got.shape == want.shape and np.all(np.isfinite(got)), what
+    if pre is not None:
+        rms = float(np.sqrt(np.mean(want.astype(np.float64) ** 2)))
+        near = np.abs(pre) <= 1e-2 * float(np.sqrt(np.mean(pre ** 2)))
+        either = np.minimum(np.abs(got - dpre), np.abs(got - 0.01 * dpre))
+        assert float(either[near].max(initial=0.0)) <= RTOL_MAX_F16W * rms, "%s: a voxel at the kink on neither branch" % what
+        got, want = got[~near], want[~near]
+    e2, em = rel_l2(got, want), max_over_rms(got, want)
+    assert e2 <= RTOL_L2_F16W and em <= RTOL_MAX_F16W, "%s: rel_l2=%.3e max/rms=%.3e" % (what, e2, em)
+    return e2, em
+
+
 def _h(a, half):
     """operand as the float16 engine sees it"""
     return a if (a is None or not half) else a.astype(np.float16).astype(np.float32)
@@ -211,9 +234,22 @@ def test_layer_gauged(eng, cin, cout, dims, act, monkeypatch):
     w64 = _h(w, half).astype(np.float64)
     y_o, dy_o = L.conv_layer_vel("conv3", _h(x, half).astype(np.float64), _h(dx, half).astype(np.float64), w64,
                                  w64 * beta.astype(np.float64)[:, None, None, None, None], b.astype(np.float64))
+    y_pre, dy_pre = y_o, dy_o
     if act:
         y_o, dy_o = L.leaky_relu_vel(y_o, dy_o)
     y, dy = eng.test_layer_gauged(x, dx, w, beta, b, act=act)
+    if half and cin % 32 == 0 and dims[0] % 2 == 0:
+        # the float16 model's Winograd-z form (conv_h3w_kernel<., ., F16>): the transformed weights U_xi and the transformed
+        # planes V = a +- b are rounded to float16 once more (half an ulp each on top of the operands' own), and NBE_WINO=0
+        # runs conv_h2q_kernel on the same operands
+        ey = _chk_f16w(y, y_o, "gauged primal, float16 Winograd-z")
+        ed = _chk_f16w(dy, dy_o, "gauged tangent, float16 Winograd-z", *((y_pre, dy_pre) if act else ()))
+        monkeypatch.setenv("NBE_WINO", "0")
+        y0, dy0 = eng.test_layer_gauged(x, dx, w, beta, b, act=act)
+        monkeypatch.delenv("NBE_WINO")
+        print("f16 wino vs f64, rel-L2 (max/rms): y %.2e (%.2e) dy away from the kink %.2e (%.2e) | direct: %.2e %.2e" % (
+            ey + ed + (rel_l2(y0, y_o), rel_l2(dy0, dy_o))))
+        y, dy = y0, dy0
     _chk(y, y_o, "gauged primal", half)
     _chk(dy, dy_o, "gauged tangent", half)
     if eng.precision == "f16x3":
@@ -223,6 +259,39 @@ def test_layer_gauged(eng, cin, cout, dims, act, monkeypatch):
         _chk(dy0, dy_o, "gauged tangent, direct kernel", half)
         print("wino vs direct: y %.2e dy %.2e | vs f64: wino %.2e %.2e direct %.2e %.2e" % (
             rel_l2(y, y0), rel_l2(dy, dy0), rel_l2(y, y_o), rel_l2(dy, dy_o), rel_l2(y0, y_o), rel_l2(dy0, dy_o)))
+
+
+@pytest.mark.parametrize("cin,cout,dims,act", [(64, 64, (8, 13, 21), True), (128, 64, (6, 12, 37), False), (64, 3, (10, 9, 40), False)])
+def test_layer_gauged_with_residual_float16(engine_factory, cin, cout, dims, act, monkeypatch):
+    """conv_1 of the float16 model: the gauged layer plus the block's skip as a residual added before the activation.  The
+    Winograd-z form adds it in its epilogue (the only conv_h3w_kernel variant with F_RES); NBE_WINO=0 runs conv_h2q_kernel."""
+    from oracle import layers as L
+    e = engine_factory(precision="f16")
+    rng = np.random.default_rng(4100 + cin + cout + dims[2])
+    x, dx = _rand(rng, cin, *dims), _rand(rng, cin, *dims)
+    w = _rand(rng, cout, cin, 3, 3, 3)
+    w /= np.sqrt((w.astype(np.float64) ** 2).sum(axis=(1, 2, 3, 4), keepdims=True)).astype(np.float32)
+    beta, b = (0.3 * _rand(rng, cout)).astype(np.float32), 0.1 * _rand(rng, cout)
+    w64 = _h(w, True).astype(np.float64)
+    y_o, dy_o = L.conv_layer_vel("conv3", _h(x, True).astype(np.float64), _h(dx, True).astype(np.float64), w64,
+                                 w64 * beta.astype(np.float64)[:, None, None, None, None], b.astype(np.float64))
+    r, dr = _rand(rng, *y_o.shape), _rand(rng, *y_o.shape)
+    y_o, dy_o = y_o + _h(r, True), dy_o + _h(dr, True)
+    y_pre, dy_pre = y_o, dy_o
+    if act:
+        y_o, dy_o = L.leaky_relu_vel(y_o, dy_o)
+    e.profile_reset(); e.profile_enable(True)
+    y, dy = e.test_layer_gauged(x, dx, w, beta, b, act=act, res=r, dres=dr)
+    e.profile_enable(False)
+    assert any(k["kernel"].startswith("conv_h1w") for k in e.profile_read()), e.profile_read()
+    ey = _chk_f16w(y, y_o, "primal")
+    ed = _chk_f16w(dy, dy_o, "tangent", *((y_pre, dy_pre) if act else ()))
+    monkeypatch.setenv("NBE_WINO", "0")
+    y0, dy0 = e.test_layer_gauged(x, dx, w, beta, b, act=act, res=r, dres=dr)
+    _chk(y0, y_o, "primal, direct kernel", True)
+    _chk(dy0, dy_o, "tangent, direct kernel", True)
+    print("f16 wino+res vs f64, rel-L2 (max/rms): y %.2e (%.2e) dy away from the kink %.2e (%.2e) | direct: %.2e %.2e" % (
+        ey + ed + (rel_l2(y0, y_o), rel_l2(dy0, dy_o))))
 
 
 def test_winograd_pack_refuses_weights_beyond_its_scale(engine_factory):
