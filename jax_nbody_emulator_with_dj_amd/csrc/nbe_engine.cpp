@@ -809,7 +809,7 @@ static void run_head(nbe_ctx* c, const Tensor& y, const Tensor& xin, const HeadO
 // Range shift (include/nbe.h, "Range").  LeakyReLU is positively homogeneous and the convolutions are linear, so the
 // network with input x and biases b satisfies f(s x; s b) = s f(x; b) for s > 0, exactly in floating point when s is a
 // power of two.  The f16-based modes use that to keep their operands where f16 has both range and precision: s = 2^k
-// brings max(|x| Dz / 6, max |b|) into [0.5, 1) whatever the caller's units are.
+// brings max(|x| Dz / 6, max |b|) into [0.5, 1) (float16) or [2^5, 2^6) (f16x3: H3_RANGE_UP) whatever the caller's units are.
 // ------------------------------------------------------------------------------------------------
 static int prepare_range(nbe_ctx* c, const float* dev_src, int64_t n, float Dz, const float* host_src = nullptr) {
     c->input_finite = true;
@@ -835,7 +835,7 @@ static int prepare_range(nbe_ctx* c, const float* dev_src, int64_t n, float Dz, 
                 int e = 0;
                 (void)std::frexp(m, &e);                        // m = f * 2^e, f in [0.5, 1)
                 e = std::max(-100, std::min(100, e));
-                s = std::ldexp(1.0f, -e);
+                s = std::ldexp(1.0f, -e + (c->prec == PREC_F16X3 ? H3_RANGE_UP : 0));
             }
         }
     }

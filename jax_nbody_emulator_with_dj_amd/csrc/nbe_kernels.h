@@ -33,6 +33,10 @@ enum Precision { PREC_F32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 inline constexpr bool prec_is_half(int prec) { return prec == PREC_F16X3 || prec == PREC_F16; }
 inline constexpr int prec_parts(int prec) { return prec == PREC_F16X3 ? 2 : 1; }
 constexpr float H3_SCALE = 2048.0f, H3_INV = 1.0f / 2048.0f;
+// f16x3: the range shift of a call places max(|x| Dz / 6, max |b|) in [2^5, 2^6) instead of [0.5, 1): conv_h3w_kernel keeps the
+// lo part of its transformed planes unscaled (nbe_kernels_wino.h, NBE_WINO_LOU), which is a normal f16 number for every
+// |value| >= 2^-3 there -- 2^-9 of the input's scale -- and leaves 2^10 of headroom above the input's scale.
+constexpr int H3_RANGE_UP = 6;
 
 // conv_h3g_kernel reads its per-group sources from a table in its arguments: 3 * Cin / 16 groups of the layer
 // + Cin_skip / 16 of a fused skip must fit

@@ -32,6 +32,16 @@
 // A stage is (phase, chunk, xi); stage s accumulates into set s & 1.  Per 16 input channels and 512 outputs: 4 stages of
 // 28 MFMAs per tile where the direct kernel runs 6.
 
+// NBE_WINO_LOU (default 1): the transformed patch carries its lo part UNSCALED (V lo = err + (a lo +- b lo) 2^-11), so the
+// product hi(w) . lo(V) takes the weights as they are -- no 2^-11 copy of every weight operand (96 of ~340 non-matrix vector
+// operations per stage and wave), no wp registers, no wait states behind those writes.  What makes that safe is the engine's
+// range shift (H3_RANGE_UP, nbe_kernels.h): activations live at 2^6 x (input max in [0.5, 1)), where the lo part of anything
+// that matters is a normal f16 number and the gradual underflow of the rest costs 2^-25 absolute, 2^-31 of the input's
+// scale.  (f16 subnormals enter the MFMA at their value: tools/micro/mfma_denorm.hip.)  -DNBE_WINO_LOU=0 keeps round 3's
+// first form (lo scaled by 2^11 like every stored lo part, weights scaled on the way) for same-device A/Bs.
+#ifndef NBE_WINO_LOU
+#define NBE_WINO_LOU (NBE_XF_F32 ? 0 : 1)
+#endif
 constexpr int NBE_MAX_WSTAGES = 32;                // 4 * Cin / 16: Cin <= 128
 constexpr int NBE_MAX_WSKIP = 16;                  // fused skip: 2 planes x Cin_block / 16 raw stages after the transformed ones
 constexpr float WINO_WSCALE = 16384.0f;            // 2^14
@@ -244,7 +254,13 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         } else {
             unsigned err, l;
             asm("v_pk_add_f16 %0, %1, %2" : "=v"(err) : "v"(x.e1), "v"(x.e2));
+#if NBE_WINO_LOU
+            const unsigned kinv = 0x10001000u;                   // packed (2^-11, 2^-11)
+            asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(l) : "v"(x.l1), "s"(kinv), "v"(err));     // unscaled: err + (a lo + sb b lo) 2^-11
+            (void)k2048;
+#else
             asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(l) : "v"(err), "s"(k2048), "v"(x.l1));
+#endif
             x.HI[r] = x.s; x.LO[r] = l;
         }
     };
@@ -352,14 +368,22 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             return;
         }
         LB(dxh, xp + HQ_XT);
+#if NBE_WINO_LOU
+        NBE_SB; MM8(Y, wh, xl, slot0, nb, px); NBE_SB;                                    // hi(w) . lo(V), lo unscaled
+#else
         NBE_SB; MM8s(Y, wp, wh, xl, slot0, nb, px); NBE_SB;                               // hi(w) 2^-11 . lo(x)
+#endif
         LB(dxl, xp + HQ_XT + HQ_PP);
         NBE_SB; MM8h(Y, wh, xh, slot0 < 0 ? -1 : slot0 + 2, nb, px, false, hooked, [&](int t) { hook(t); }); NBE_SB;       // hi . hi
         LA(wl, wa + CT + aP);
         NBE_SB; MM8h(DY, wh, dxh, slot0 < 0 ? -1 : slot0 + 4, nb, px, false, hooked, [&](int t) { hook(8 + t); }); NBE_SB;
         after3();
         mid();
+#if NBE_WINO_LOU
+        NBE_SB; MM8(DY, wh, dxl, -1, nb, px); NBE_SB;
+#else
         NBE_SB; MM8(DY, wp, dxl, -1, nb, px); NBE_SB;
+#endif
         preXl(); preW();                                                                  // (not earlier: registers)
         NBE_SB; MM8(Y, wl, xh, -1, nb, px); NBE_SB;                                       // lo(w) . hi(x)
         preXh();
@@ -408,12 +432,16 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
             LB(xl, xb + SH5 + bP32 + HQ_PP); LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
             NBE_SB; MM8(DY, a1, b1d, -1, 0, false); NBE_SB;
         } else {
+#if NBE_WINO_LOU
+        NBE_SB; MM8(Y, a1, b1x, -1, 0, false); NBE_SB;                                    // [wh | wh] . [V hi | V lo]
+#else
         {
             const _Float16 m1 = ks ? kInv : (_Float16)1.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a1[mt] = a1[mt] * m1;
         }
         NBE_SB; MM8(Y, a1, b1x, -1, 0, false, true); NBE_SB;
+#endif
         LA(a2, aS + CT);                                                                  // (only now: four A operand sets at once do not fit)
         LB(xl, xb + SH5 + bP32 + HQ_PP);
         NBE_SB; MM8(DY, a1, b1d, -1, 0, false); NBE_SB;

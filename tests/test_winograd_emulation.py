@@ -65,3 +65,21 @@ def test_packed_f16_transform_matches_the_float32_one():
         exact = (ah + al / 2048.0) + sb * (bh + bl / 2048.0)
         err = np.abs(s + lo / 2048.0 - exact) / (np.abs(a) + np.abs(b))
         assert err.max() <= 2.0 ** -21, (sb, err.max())
+
+
+def test_unscaled_lo_part_of_the_transformed_planes():
+    """The default build keeps the lo part of V = a +- b unscaled (NBE_WINO_LOU: V lo = err + (a lo +- b lo) 2^-11), so that the
+    product hi(w) . lo(V) needs no 2^-11 copy of the weights.  Below 2^-14 that part is a subnormal f16 number (2^-25 absolute);
+    the engine's range shift (H3_RANGE_UP = 6: the input's maximum in [32, 64)) keeps activations where that does not show:
+    same error as the scaled form from an activation RMS of 64 down to 1, within 10 % at 1/8 (2^-9 of the input's scale)."""
+    x, w = _case(32, 16, (6, 7, 9), 5)
+    for rms, slack in ((64.0, 1.02), (8.0, 1.02), (1.0, 1.02), (0.125, 1.10)):
+        xs = W.f32(x * rms)
+        ye = W.conv_exact(xs, w)
+        e_s, e_u = W.rel(W.conv_winograd_z(xs, w), ye), W.rel(W.conv_winograd_z(xs, w, unscaled_lo=True), ye)
+        assert e_u <= slack * e_s + 1e-9 and e_u <= 6e-7, (rms, e_s, e_u)
+    # exact arithmetic: the form is still the convolution
+    rng = np.random.default_rng(6)
+    xi = rng.integers(-8, 9, size=(16, 6, 5, 7)).astype(np.float64) * 64.0
+    wi = rng.integers(-4, 5, size=(8, 16, 3, 3, 3)).astype(np.float64) / 64.0
+    assert np.array_equal(W.conv_winograd_z(xi, wi, S=2.0 ** 6, unscaled_lo=True), W.conv_exact(xi, wi))

@@ -49,16 +49,20 @@ def conv_f16x3_direct(x, w):
     return f32(ym + yc / 2048.0)
 
 
-def transform_f16(ah, al, bh, bl, sb):
-    """V = a + sb b on (hi, lo * 2^11) parts in f16 arithmetic, as xf_step does it: returns (s, lo)."""
+def transform_f16(ah, al, bh, bl, sb, unscaled=False):
+    """V = a + sb b on (hi, lo * 2^11) parts in f16 arithmetic, as xf_step does it: returns (s, lo).
+    unscaled (NBE_WINO_LOU, the default build): lo = err + (a lo + sb b lo) 2^-11, NOT times 2^11 -- subnormal below 2^-14."""
     s = f16(ah + sb * bh)
     bb = f16(s - ah)
     err = f16(f16(ah - f16(s - bb)) + f16(sb * bh - bb))          # exact (TwoSum)
+    if unscaled:
+        return s, f16(f16(al + sb * bl) / 2048.0 + err)           # fma: one rounding (gradual underflow)
     lo = f16(err * 2048.0 + f16(al + sb * bl))                    # fma: one rounding
     return s, lo
 
 
-def conv_winograd_z(x, w, S=2.0 ** 14, transform='f16'):
+def conv_winograd_z(x, w, S=2.0 ** 14, transform='f16', unscaled_lo=False):
+    """unscaled_lo: the default build's form -- the lo part of V is kept unscaled and meets the weights' hi part as it is."""
     cout, cin = w.shape[:2]
     D, H, W = x.shape[1:]
     Do, Ho, Wo = D - 2, H - 2, W - 2
@@ -78,14 +82,16 @@ def conv_winograd_z(x, w, S=2.0 ** 14, transform='f16'):
 
         def run(acc, xi):
             if transform == 'f16':
-                Vh, Vl = transform_f16(xh[:, 2 * p + PA[xi]], xl[:, 2 * p + PA[xi]], xh[:, 2 * p + PB[xi]], xl[:, 2 * p + PB[xi]], SB[xi])
+                Vh, Vl = transform_f16(xh[:, 2 * p + PA[xi]], xl[:, 2 * p + PA[xi]], xh[:, 2 * p + PB[xi]], xl[:, 2 * p + PB[xi]], SB[xi],
+                                       unscaled=unscaled_lo)
             else:
                 Vh, Vl = split_scaled(V[xi])
+            Wlo = Uh if unscaled_lo else Uhp                      # what multiplies the lo part of V
             for c0 in range(0, cin, 16):
                 for dy in range(3):
                     for dx in range(3):
                         sl = (slice(c0, c0 + 16), slice(dy, dy + Ho), slice(dx, dx + Wo))
-                        acc = f32(acc + np.einsum('oi,iyx->oyx', Uhp[xi][:, c0:c0 + 16, dy, dx], Vl[sl]))
+                        acc = f32(acc + np.einsum('oi,iyx->oyx', Wlo[xi][:, c0:c0 + 16, dy, dx], Vl[sl]))
                         acc = f32(acc + np.einsum('oi,iyx->oyx', Uh[xi][:, c0:c0 + 16, dy, dx], Vh[sl]))
                         acc = f32(acc + np.einsum('oi,iyx->oyx', Ul[xi][:, c0:c0 + 16, dy, dx], Vh[sl]))
             return acc
@@ -117,3 +123,7 @@ if __name__ == "__main__":
     for s in (1e-3, 30.0, 1e3):
         xs = f32(x * s)
         print("  input scale %g: %.2e" % (s, rel(conv_winograd_z(xs, w), conv_exact(xs, w))))
+    print("unscaled lo part of V (default build), activation RMS as the range shift leaves it:")
+    for s in (2.0 ** 6, 8.0, 1.0, 2.0 ** -3, 2.0 ** -6):
+        xs = f32(x * s)
+        print("  activation RMS %-8g rel-L2 %.2e" % (s, rel(conv_winograd_z(xs, w, unscaled_lo=True), conv_exact(xs, w))))
