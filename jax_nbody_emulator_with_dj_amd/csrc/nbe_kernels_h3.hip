@@ -34,7 +34,9 @@ __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         hi[e] = (_Float16)v[e];
-        lo[e] = (_Float16)((v[e] - (float)hi[e]) * H3_SCALE);
+        // (v - hi) 2^11 as one mixed-precision FMA on the f16 half where it lies: v 2^11 is exact, hi 2^11 is exact and so is
+        // their difference -- the same bits as (v - float(hi)) * 2^11, two vector operations fewer per element
+        lo[e] = (_Float16)__builtin_fmaf((float)hi[e], -H3_SCALE, v[e] * H3_SCALE);
     }
 }
 __device__ __forceinline__ f32x4 join4(const half4 hi, const half4 lo) {

@@ -39,6 +39,18 @@
 // that matters is a normal f16 number and the gradual underflow of the rest costs 2^-25 absolute, 2^-31 of the input's
 // scale.  (f16 subnormals enter the MFMA at their value: tools/micro/mfma_denorm.hip.)  -DNBE_WINO_LOU=0 keeps round 3's
 // first form (lo scaled by 2^11 like every stored lo part, weights scaled on the way) for same-device A/Bs.
+// NBE_WINO_ZROW (default 1): the [lo(w) | 0] operand of the single tap reads its zero half from a zeroed kilobyte of LDS behind
+// the patch buffers instead of being cleared by sixteen v_cndmask per stage (and their wait states before the MFMA);
+// the weight DMA's lane offset lives in a register (one of those the unscaled lo part freed).
+#ifndef NBE_EPI_MAX
+#define NBE_EPI_MAX 1
+#endif
+#ifndef NBE_WINO_ZROW
+#define NBE_WINO_ZROW 1
+#endif
+#ifndef NBE_WINO_ITEMREG
+#define NBE_WINO_ITEMREG 1
+#endif
 #ifndef NBE_WINO_LOU
 #define NBE_WINO_LOU (NBE_XF_F32 ? 0 : 1)
 #endif
@@ -88,6 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     static_assert(!(F16 && (NOVEL || SKIP)), "the float16 form has neither a fused skip nor a displacement-only variant");
     typedef HGGeom<false, true, false> G;
     constexpr int NW = 8, CT = 64, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = 4, NT = 2, NTILE = 8;
+    constexpr int ZROW = G::LDS_UNITS;                           // 64 zeroed units behind the patch buffers (NBE_WINO_ZROW)
     f32x4* lds = lds_h3;
     const half8* L8 = (const half8*)lds_h3;
     half8* L8w = (half8*)lds_h3;
@@ -131,10 +144,13 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         const WinoSrc e = a.st[s];
         nx.xa = e.xa + to; nx.xb = e.xb + to; nx.dxd = e.dxd; nx.psb = e.psb; nx.w0 = e.w + (SKIP && s >= nst ? wcs : wcm); nx.sb = e.sb;
     };
+    unsigned lane16 = (unsigned)lane << 4;
+    asm volatile("" : "+v"(lane16));
     auto dma_w = [&](int buf, int t) {                           // 36 wave-instructions of weights, 5 slots per wave
         const int n = wave + NW * t;
         unsigned l16 = (unsigned)lane;
-        asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(l16));       // recomputed at every use: held in a register it is spilled
+        if (NBE_WINO_ZROW && !F16) l16 = lane16;
+        else asm volatile("v_lshlrev_b32 %0, 4, %0" : "+v"(l16));   // recomputed at every use: held in a register it is spilled
         if (n < G::NWI) dma16s(nx.w0 + (long)n * 1024, l16, lds + buf * WGU + n * 64);
     };
     // ---- a raw stage (SKIP): 8 wave-instructions of weights (W_s, dW_s~ of the chunk: one per wave) and 24 + 24 of the x and
@@ -158,14 +174,38 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // lo plane each, three per wave; an item is four 16-byte loads per lane (a hi, a lo, b hi, b lo), 8 channels of
     // V = a + sb * b in float32, and two 16-byte LDS stores.
     // (per-lane offsets are recomputed at every use -- a dozen VALU operations per item -- instead of held in registers)
+    // ITEMREG (since the unscaled lo part freed the scaled-weight registers): the three items' unit and plane offset live in
+    // six registers for the whole workgroup -- before, a dozen VALU operations per item and stage recomputed them.  (The
+    // float16 form has no registers to spare: there they are recomputed.)
+    constexpr bool ITEMREG = NBE_WINO_ITEMREG && !F16;
+    int it_uu[3] = {0, 0, 0};
+    unsigned it_go[3] = {0u, 0u, 0u};
+    if (ITEMREG) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int u = ((wave + NW * j) % 6) * 64 + lane;
+            it_uu[j] = u < HP_PL ? u : HP_PL - 1;
+            const int row = (it_uu[j] * 241) >> 13, col = it_uu[j] - row * HP_RS;   // uu / 34 for uu < 384
+            it_go[j] = (unsigned)(row * a.W + col) * 16u;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(it_uu[j]), "+v"(it_go[j]));   // held, not rematerialised
+    }
     auto item_unit = [&](int j, bool& valid) {                   // unit 0..339 of the 10 x 34 patch plane this lane handles in item j
+        if (ITEMREG) {
+            valid = lane < HP_PL - ((wave + NW * j) % 6) * 64;
+            return it_uu[j];
+        }
         int l = lane;
         asm volatile("" : "+v"(l));                              // (or the compiler hoists the offsets out of the loop and spills them)
         const int u = ((wave + NW * j) % 6) * 64 + l;
         valid = u < HP_PL;
         return valid ? u : HP_PL - 1;
     };
-    auto item_goff = [&](int uu) {                               // byte offset of that unit in an input plane
+    auto item_goff_j = [&](int j) {                              // byte offset of that unit in an input plane
+        if (ITEMREG) return it_go[j];
+        bool v;
+        const int uu = item_unit(j, v);
         const int row = (uu * 241) >> 13, col = uu - row * HP_RS;   // uu / 34 for uu < 384
         return (unsigned)(row * a.W + col) * 16u;
     };
@@ -177,8 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         const long po = ((n / 12) ? nx.dxd : 0) + (long)(((n % 12) / 6) * 2) * nx.psb;
         const char* pa = nx.xa + po;
         const char* pb = nx.xb + po;
-        bool valid;
-        const unsigned go = item_goff(item_unit(j, valid));
+        const unsigned go = item_goff_j(j);
         // buffer loads: wave-uniform base in a resource descriptor (SGPRs) + 32-bit lane offset (+ the lo plane's distance as
         // the scalar offset) -- the compiler's own global loads keep a 64-bit address per lane and load.  Unlike loads
         // issued from asm statements these are visible to the compiler's vmcnt bookkeeping (spill-safe, counted waits).
@@ -442,15 +481,23 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         }
         NBE_SB; MM8(Y, a1, b1x, -1, 0, false, true); NBE_SB;
 #endif
+#if NBE_WINO_ZROW
+        LA(a2, ks ? ZROW + c : aS + CT);                                                  // [wl | 0]: the K half of the lo plane reads zeros
+#else
         LA(a2, aS + CT);                                                                  // (only now: four A operand sets at once do not fit)
+#endif
         LB(xl, xb + SH5 + bP32 + HQ_PP);
         NBE_SB; MM8(DY, a1, b1d, -1, 0, false); NBE_SB;
         LB(xh, xb + SH5 + bP32); LA(wh, wb + 5 * TAPU + aP);
+#if NBE_WINO_ZROW
+        NBE_SB; MM8(Y, a2, b1x, -1, 0, false); NBE_SB;
+#else
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a2[mt] = ks ? zero : a2[mt];
         // (transforming item 1 under the single tap's last products instead, 7 / 5 / 7 products between loads and first use
         // rather than 6 / 8 / 4, was measured: +-0: the loads' latency is not exposed)
         NBE_SB; MM8(Y, a2, b1x, -1, 0, false, true); NBE_SB;
+#endif
         MM8(DY, a2, b1d, -1, 0, false); NBE_SB;
         }
         pair(Y, DY, -1, nb, px, wb + 5 * TAPU, xb + SH5 + bP32,                           // taps (5,6)
@@ -503,6 +550,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 
     // ---- prologue: stage 0
     {
+        if (NBE_WINO_ZROW && !F16 && tid < 64) L8w[ZROW + tid] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         set_next(0);
 #pragma unroll
         for (int k = 0; k < G::NWS; ++k) dma_w(0, k);
@@ -584,6 +632,11 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
     // that only the draining of the stores issued in between can satisfy)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(bv[mt]), "+v"(be[mt]), "+v"(gv[mt]));
+    // (the 64-bit part of every store address -- unit, plane pitch, K half -- once per workgroup; per tile only + 16 o)
+    long ob_mt[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ob_mt[mt] = (long)(a.out_g0 + (F16 ? 1 : 2) * unit[mt]) * a.out_pstride * 16 + 8 * kh;
+    const long ol_off = a.out_pstride * 16;
     auto epilogue = [&](f32x4 (&Y)[NTILE], f32x4 (&DY)[NTILE], int z) {
         int o[NT];
         bool ook[NT], ook2[NT];                                  // NOVEL: the second row block, eight rows further down
@@ -630,7 +683,9 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         dv[e] = v[e] > 0.f ? dv[e] : 0.01f * dv[e];
-                        v[e] = v[e] >= 0.f ? v[e] : 0.01f * v[e];
+                        // max(v, 0.01 v) = (v >= 0 ? v : 0.01 v) without the compare -> vcc -> select chain and its wait states
+                        // (the float16 form keeps the select: there the compiler pairs the compares)
+                        v[e] = (F16 || !NBE_EPI_MAX) ? (v[e] >= 0.f ? v[e] : 0.01f * v[e]) : __builtin_fmaxf(v[e], 0.01f * v[e]);
                     }
                 }
                 if (gauge) {
@@ -639,7 +694,7 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
                 }
                 if (F16) {                                       // one f16 plane per unit; the residual was added before the activation
                     if (uok[mt] && ook[nt]) {
-                        const long ob = ((long)(a.out_g0 + unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
+                        const long ob = ob_mt[mt] + (long)o[nt] * 16;
                         half4 h, dh;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { h[e] = (_Float16)v[e]; dh[e] = (_Float16)dv[e]; }
@@ -653,8 +708,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
                         dv[e] = acc_read(DY[t][e]) * a.inv_scale + bv[mt][e];
                         if (act) dv[e] = dv[e] >= 0.f ? dv[e] : 0.01f * dv[e];
                     }
-                    const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
-                    const long ol = ob + a.out_pstride * 16;
+                    const long ob = ob_mt[mt] + (long)o[nt] * 16;
+                    const long ol = ob + ol_off;
                     const long r8 = (long)HP_ROWS * a.Wo * 16;
                     half4 hi, lo;
                     if (uok[mt] && ook[nt]) {
@@ -669,8 +724,8 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
                     }
                 } else
                 if (uok[mt] && ook[nt]) {
-                    const long ob = ((long)(a.out_g0 + 2 * unit[mt]) * a.out_pstride + (long)o[nt]) * 16 + 8 * kh;
-                    const long ol = ob + a.out_pstride * 16;
+                    const long ob = ob_mt[mt] + (long)o[nt] * 16;
+                    const long ol = ob + ol_off;
                     half4 hi, lo;
                     split4(v, hi, lo);
                     *(half4*)((char*)a.y + ob) = hi;
@@ -733,7 +788,8 @@ void launch_pack_h3w(const float* w_oidhw, int cout, int cin, int cin_pad, int c
 static int launch_h3w(const ConvKArgs& ka_in, const float* ww, const float* wws, long wws_set_floats, int ctiles, hipStream_t s,
                       bool novel = false, bool f16 = false) {
     typedef HGGeom<false, true, false> G;
-    constexpr size_t smem = (size_t)G::LDS_UNITS * 16;
+    constexpr size_t smem = (size_t)(G::LDS_UNITS + 64) * 16;   // + the zeroed kilobyte (NBE_WINO_ZROW)
+    static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     ConvKArgs ka = ka_in;
     if (f16) {                                                   // 16-channel chunks -> 32-channel stages
         if (novel || ka.nskip > 0 || (ka.nchunk & 1) || (ka.csplit < ka.nchunk && (ka.csplit & 1))) return 1;
