@@ -221,9 +221,24 @@ def test_float16_mode(engine_factory, small, monkeypatch):
     e = engine_factory(mid_chan=mid, compute_vel=True, precision="f16")
     e.load_params(p, premodulated=False)
     e.set_cosmology(OM, DZ)
+    e.profile_reset(); e.profile_enable(True)
     d, v = e.forward(x, DZ, VF)
+    e.profile_enable(False)
+    names = [k["kernel"] for k in e.profile_read()]
+    # production width: the gauged 3x3x3 layers run the Winograd-z form (conv_h3w_kernel<., ., F16>) wherever a launch has an
+    # even number of planes; NBE_WINO=0 puts all of them on conv_h2q_kernel -- both within the float16 tolerances
+    assert any(n.startswith("conv_h1w<FLAT3") for n in names), names
     print("f16 mid64: disp rel_l2 %.3e vel rel_l2 %.3e" % (rel_l2(d, gold["net64_disp"]), rel_l2(v, gold["net64_vel"])))
     assert rel_l2(d, gold["net64_disp"]) <= 2e-3 and rel_l2(v, gold["net64_vel"]) <= 4e-2
+    monkeypatch.setenv("NBE_WINO", "0")
+    e.profile_reset(); e.profile_enable(True)
+    d0_, v0_ = e.forward(x, DZ, VF)
+    e.profile_enable(False)
+    monkeypatch.delenv("NBE_WINO")
+    assert not any(k["kernel"].startswith("conv_h1w") for k in e.profile_read())
+    print("f16 mid64, direct kernels: disp rel_l2 %.3e vel rel_l2 %.3e; Winograd-z vs direct %.3e / %.3e" % (
+        rel_l2(d0_, gold["net64_disp"]), rel_l2(v0_, gold["net64_vel"]), rel_l2(d, d0_), rel_l2(v, v0_)))
+    assert rel_l2(d0_, gold["net64_disp"]) <= 2e-3 and rel_l2(v0_, gold["net64_vel"]) <= 4e-2
 
 
 def test_full_width_c1_slice(engine_factory):

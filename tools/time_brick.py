@@ -9,9 +9,13 @@
 
   --link GB/s   make every exchange take as long on the communication stream as that link rate would (a spin kernel behind
                 the copy): the timeline a real xGMI hop produces -- whether the compute stream ever waits for a transfer shows
-                as the difference to the run without it.  --link 0 (default): copies only."""
+                as the difference to the run without it.  --link 0 (default): copies only.
+  --box 1024    one rank's z-slab brick of the 1024^3 box on eight cards (BASELINE config 5): (128, 1024, 1024) with the
+                exchanges of that size (the whole box does not fit one card as one tile: N = 8 only, efficiency against
+                eight times the brick's own compute is not printed)."""
 import sys, time
 LINK = float(sys.argv[sys.argv.index("--link") + 1]) if "--link" in sys.argv else 0.0
+BOX = int(sys.argv[sys.argv.index("--box") + 1]) if "--box" in sys.argv else 512
 sys.path.insert(0, ".")
 import torch
 from jax_nbody_emulator_with_dj_amd.engine import Engine
@@ -20,9 +24,9 @@ from jax_nbody_emulator_with_dj_amd import StyleNBodyEmulatorVelCore
 e = Engine(device=0)
 e.load_params(StyleNBodyEmulatorVelCore().init(1), False)
 e.set_cosmology(0.3, 0.77)
-N = 512
+N = BOX
 t1 = None
-for n in (1, 2, 4, 8):
+for n in ((1, 2, 4, 8) if N <= 512 else (8,)):
     b = (N // n, N, N)
     if n == 1:
         box = torch.randn((3,) + b, device="cuda")
@@ -65,11 +69,11 @@ for n in (1, 2, 4, 8):
         e.brick_finish(r2_lo, r2_hi, q_lo, q_hi, 0.77, 50.0, disp, vel, skip_ready=ev_skip)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(("link emulated at %g GB/s: " % LINK if LINK > 0 else "") + "N=%d z-slab brick %s, exchanges of %.0f + %.0f + %.0f + %.0f MB per direction: %.3f s -> %.1f Mvox/s for the job, efficiency %.2f"
-          % (n, b, e.brick_halo_bytes(b, 0) / 1e6, n1 / 1e6, n2 / 1e6, n3 / 1e6, dt, N ** 3 / dt / 1e6, t1 / (n * dt)), flush=True)
+          % (n, b, e.brick_halo_bytes(b, 0) / 1e6, n1 / 1e6, n2 / 1e6, n3 / 1e6, dt, N ** 3 / dt / 1e6, t1 / (n * dt) if t1 else float("nan")), flush=True)
     del H, disp, vel, s_lo, s_hi, r_lo, r_hi, s2_lo, s2_hi, r2_lo, r2_hi, k_lo, k_hi, q_lo, q_hi
     torch.cuda.empty_cache()
 # the padded scheme of round 1 for comparison
-for name, grid in [] if LINK > 0 else (("N=8 (2,2,2)", (2, 2, 2)), ("N=4 (4,1,1)", (4, 1, 1))):
+for name, grid in [] if (LINK > 0 or N > 512) else (("N=8 (2,2,2)", (2, 2, 2)), ("N=4 (4,1,1)", (4, 1, 1))):
     b = tuple(N // g for g in grid)
     pa = tuple(48 if g > 1 else 0 for g in grid)
     H = torch.randn((3,) + tuple(bb + 2 * p for bb, p in zip(b, pa)), device="cuda")
