@@ -76,12 +76,13 @@ int nbe_set_precision(nbe_ctx* ctx, int precision);
  * precision above 6.1e-5), while the reference's float32 arithmetic (style_layers_vel.py:103-105) has float32's range.
  * The engine therefore shifts every call into f16's comfortable range: LeakyReLU is positively homogeneous and the
  * convolutions are linear, so f(s x; s b) = s f(x; b) for the network f with input x and biases b, exactly in floating
- * point for s = 2^k.  Per call k is chosen such that max(max|x| * Dz / 6, max|b|) * 2^k lies in [0.5, 1): a reduction
- * over the input, the input scaled in the gather, the biases scaled on the device, 2^-k applied in the head.  Valid
- * inputs: any finite float32 box -- parity with the float64 oracle is tested over 24 decades of input scale
- * (tests/test_gpu_range.py).  What remains out of range is a network whose activations grow beyond 65504 times its
- * largest input / bias (weights far from the unit-norm filters the modulation produces); then an infinity or a NaN
- * reaches the head, which flags it:
+ * point for s = 2^k.  Per call k is chosen such that max(max|x| * Dz / 6, max|b|) * 2^k lies in [0.5, 1) (NBE_PREC_F16)
+ * or in [32, 64) (NBE_PREC_F16X3: the Winograd-z kernel keeps the lo part of its transformed planes unscaled, a normal f16
+ * number for every |value| >= 2^-9 of the input's scale there): a reduction over the input, the input scaled in the
+ * gather, the biases scaled on the device, 2^-k applied in the head.  Valid inputs: any finite float32 box -- parity
+ * with the float64 oracle is tested over 24 decades of input scale (tests/test_gpu_range.py).  What remains out of
+ * range is a network whose activations grow beyond 65504 (F16) / 1023 (F16X3) times its largest input / bias (weights far
+ * from the unit-norm filters the modulation produces); then an infinity or a NaN reaches the head, which flags it:
  *   - host arrays in/out: the call returns NBE_ERANGE (2) instead of the fields;
  *   - device pointers (asynchronous calls): nbe_check_finite() synchronises and returns NBE_ERANGE if any call since
  *     the last check produced a non-finite value from a finite input.  The Python shim calls it after every call and

@@ -20,9 +20,11 @@ def _gpu_available():
         return False
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture(scope="module")
 def engine_factory():
-    """Engines through the C ABI.  On a GPU box a missing libnbe.so is a hard failure, never a skip."""
+    """Engines through the C ABI.  On a GPU box a missing libnbe.so is a hard failure, never a skip.
+    (Module scope: an engine keeps its workspace -- tens of GB after a 224^3 sub-box -- until it is closed, and the full-size
+    tests of later modules plan their tiles into the memory that is free.)"""
     from jax_nbody_emulator_with_dj_amd.engine import Engine
     made = []
 

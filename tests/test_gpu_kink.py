@@ -186,6 +186,7 @@ def test_subbox_224_matches_float64_fixture_and_cone_oracle(engine_factory, prec
         ed = rel_l2(got, want), float(np.abs(got - want).max() / rms_d)
         print("224^3 sub-box %s displacement-only %s: %.2e / %.2e" % (prec, name, *ed))
         assert ed[0] <= 2e-5 and ed[1] <= 2e-4, (name, ed)
+    en.close()                                                  # (its workspace with it)
     if prec == "f16x3":         # (strict float32 takes the same schedule through the same probe: config 1 covers it causally)
         d_o, v_o, st = kink.oracle_cone(p, kink.cone_input_valid(x, o, 8), OM, DZ, VF, br)
         kink.assert_cone("224^3 sub-box %s block %s" % (prec, o), _block(d, o, 8), _block(v, o, 8), d_o, v_o, st, rms_d=rms_d, rms_v=rms_v)
