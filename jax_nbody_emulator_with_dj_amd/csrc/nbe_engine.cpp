@@ -707,7 +707,7 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
         return fail("internal: concat geometry mismatch in %s", name);
     // f16x3 with velocity and Cin <= 64: all eight parities in one launch (up_h3_kernel: the input is read once)
     const bool up8_off = getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0;                 // A/B switch
-    const bool up8 = c->prec == PREC_F16X3 && c->vel && L->pw.cin_pad <= 64 && !up8_off;
+    const bool up8 = prec_is_half(c->prec) && c->vel && L->pw.cin_pad <= 64 && !up8_off;
     const int out_g0 = g0 >= 0 ? g0 : c->mid / (c->prec == PREC_F16 ? 8 : 4);
     for (int p = 0; p < (up8 ? 1 : 8); ++p) {
         ConvLaunch cl; cl.in = x.p; cl.in_off = ((int64_t)xcrop * x.p.W + xcrop);
@@ -2875,7 +2875,7 @@ static int test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x,
         else if (kind == 2) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; rc = run_conv(c, L, cl, has_dx); }
         else {
             // as upblock(): one launch for all eight parities where up_h3_kernel applies
-            const bool up8 = c->prec == PREC_F16X3 && vel && has_dx && pw.cin_pad <= 64 && !(getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0);
+            const bool up8 = prec_is_half(c->prec) && vel && has_dx && pw.cin_pad <= 64 && !(getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0);
             for (int p = 0; p < (up8 ? 1 : 8) && !rc; ++p) {
                 ConvLaunch u = cl; u.Dv = D; u.Hv = H; u.Wv = W; u.osz = 2; u.oz = (p >> 2) & 1; u.oy = (p >> 1) & 1; u.ox = p & 1;
                 u.set = up8 ? -1 : p;

@@ -391,14 +391,22 @@ __global__ __launch_bounds__(512, 2) void conv_h3_kernel(ConvKArgs a) {
 // after the first, long after L2 had turned over: WRITE_SIZE 1.5 x the algorithmic bytes, and the kernel ran at the
 // write bandwidth that pattern allows -- tools/micro/write_bw.hip: 4.7 TB/s for 32 interleaved plane streams.)
 // Stage = (position half, parity pair, chunk): weights of both parities, 16 KB, double-buffered.
+// SPLIT = false: the float16 model (one plane per eight channels, one MFMA per product): half the LDS image, two workgroups per
+// CU, a third of the MFMAs -- instead of eight launches of the general 1x1x1 kernel that each read the whole input.
 constexpr int UP_XV = 256;                           // positions per workgroup
-constexpr int UP_XC = 2 * 4 * UP_XV;                 // units of one resident chunk: (X, dX) x 4 units x 256
 constexpr int UP_MAXCH = 4;                          // Cin <= 64
-constexpr int UP_WS = 2 * 2 * 4 * 64;                // units of one weight stage: 2 parities x (W, dW) x 4 units x 64 couts
-constexpr int UP_WBASE = UP_MAXCH * UP_XC;
-constexpr int UP_LDS_UNITS = UP_WBASE + 2 * UP_WS;   // 10240 units = 163,840 B: all of the CU's LDS
+template <bool SPLIT> struct UpGeom {
+    static constexpr int UN = SPLIT ? 4 : 2;             // 16-byte units per position and 16-channel chunk (2 h + part | h)
+    static constexpr int XC = 2 * UN * UP_XV;            // units of one resident chunk: (X, dX) x UN units x 256
+    static constexpr int WS = 2 * 2 * UN * 64;           // units of one weight stage: 2 parities x (W, dW) x UN units x 64 couts
+    static constexpr int WBASE = UP_MAXCH * XC;
+    static constexpr int LDS_UNITS = WBASE + 2 * WS;     // f16x3: 10240 units = 163,840 B, all of the CU's LDS; float16: half
+};
 
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
+    constexpr int UN = UpGeom<SPLIT>::UN, UP_XC = UpGeom<SPLIT>::XC, UP_WS = UpGeom<SPLIT>::WS, UP_WBASE = UpGeom<SPLIT>::WBASE;
+    constexpr int PS = SPLIT ? 2 : 1;                        // planes per channel half: hi, lo | one
     f32x4* lds = lds_h3;
     const half8* L8 = (const half8*)lds_h3;
     const int tid = threadIdx.x;
@@ -416,23 +424,23 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     // 32 wave-instructions per chunk, 4 per wave
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int n = wave + 8 * k;                       // 0..31: tensor (n >> 4), unit ((n >> 2) & 3), quarter (n & 3)
-            const int t = n >> 4, u = (n >> 2) & 3, qd = n & 3;
+        for (int k = 0; k < UN; ++k) {
+            const int n = wave + 8 * k;                       // 0..8 UN - 1: tensor, unit, quarter (n & 3)
+            const int t = n / (4 * UN), u = (n >> 2) % UN, qd = n & 3;
             const long v = q0 + a.in_off + qd * 64 + lane;
-            const char* src = (const char*)(t ? a.dx : a.x) + (((long)c * 4 + u) * a.in_pstride + v) * 16;
-            dma16((const float*)src, lds + c * UP_XC + (t * 4 + u) * UP_XV + qd * 64);
+            const char* src = (const char*)(t ? a.dx : a.x) + (((long)c * UN + u) * a.in_pstride + v) * 16;
+            dma16((const float*)src, lds + c * UP_XC + (t * UN + u) * UP_XV + qd * 64);
         }
     }
     // ---- weights of stage st: parities 2 pp and 2 pp + 1 of chunk c: [parity][W | dW][unit 4][64 couts] = 16 wave-instructions
     auto dma_w = [&](int st) {
         const int c = st % nchunk, pp = (st / nchunk) & 3;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int n = wave + 8 * k;                       // 0..15: parity (n >> 3), set ((n >> 2) & 1), unit (n & 3)
-            const int par = n >> 3, d = (n >> 2) & 1, m = n & 3;
+        for (int k = 0; k < UN / 2; ++k) {
+            const int n = wave + 8 * k;                       // 0..4 UN - 1: parity, set (W | dW), unit
+            const int par = n / (2 * UN), d = (n / UN) & 1, m = n % UN;
             const char* src = (const char*)(d ? a.dw : a.w) + (long)(2 * pp + par) * a.set_stride +
-                              (((long)ct * nchunk + c) * 256 + m * 64 + lane) * 16;
+                              (((long)ct * nchunk + c) * (UN * 64) + m * 64 + lane) * 16;
             dma16((const float*)src, lds + UP_WBASE + (st & 1) * UP_WS + n * 64);
         }
     };
@@ -454,12 +462,21 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
         if (st + 1 < nstage) dma_w(st + 1);
         const half8* wb = L8 + UP_WBASE + (st & 1) * UP_WS;
         const half8* xb = L8 + c * UP_XC;
-        const int xo = (2 * lh) * UP_XV + half * 128 + jq * 32 + li;
-        const half8 xh = xb[xo], xl = xb[xo + UP_XV], dxh = xb[4 * UP_XV + xo], dxl = xb[4 * UP_XV + xo + UP_XV];
+        const int xo = (PS * lh) * UP_XV + half * 128 + jq * 32 + li;
+        const half8 xh = xb[xo], dxh = xb[UN * UP_XV + xo];
+        half8 xl = xh, dxl = dxh;
+        if (SPLIT) { xl = xb[xo + UP_XV]; dxl = xb[UN * UP_XV + xo + UP_XV]; }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {                      // x parity jt: its own weights, the same activations
-            const int wo = jt * 512 + (2 * lh) * 64 + 32 * it + li;
-            const half8 wh = wb[wo], wl = wb[wo + 64], dwh = wb[256 + wo], dwl = wb[256 + wo + 64];
+            const int wo = jt * (2 * UN * 64) + (PS * lh) * 64 + 32 * it + li;
+            const half8 wh = wb[wo], dwh = wb[UN * 64 + wo];
+            if (!SPLIT) {                                    // float16: y += w.x, dy += dw.x + w.dx
+                ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
+                dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xh, dm[jt], 0, 0, 0);
+                dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxh, dm[jt], 0, 0, 0);
+                continue;
+            }
+            const half8 wl = wb[wo + 64], dwl = wb[UN * 64 + wo + 64];
             ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
             yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, yc[jt], 0, 0, 0);
             yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, yc[jt], 0, 0, 0);
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             const long o0 = okq ? ((long)(2 * z + (pp >> 1)) * a.Ho + (2 * yy + (pp & 1))) * a.Wo + 2 * xx : 0;
             const long o[2] = {o0, o0 + (okq ? 1 : 0)};
             const bool ok[2] = {okq, okq};
-            h3_store2<true, true>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
+            h3_store2<true, SPLIT>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
             zero_acc();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
@@ -492,17 +509,18 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     }
 }
 
+template <bool SPLIT>
 static int launch_up_h3(ConvKArgs ka, int ctiles, hipStream_t s) {
-    constexpr size_t smem = (size_t)UP_LDS_UNITS * 16;
+    constexpr size_t smem = (size_t)UpGeom<SPLIT>::LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     if (ka.nchunk > UP_MAXCH) return 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)up_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)up_h3_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
-    hipLaunchKernelGGL(up_h3_kernel, grid, block, smem, s, ka);
+    hipLaunchKernelGGL(up_h3_kernel<SPLIT>, grid, block, smem, s, ka);
     return 0;
 }
 
@@ -2218,7 +2236,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         return 1;
 #endif
     } else if (pw.mode == MODE_FLAT1) {
-        if (ka.up8) return (split && vel && has_dx) ? launch_up_h3(ka, ct, s) : 1;      // all eight parities in one launch
+        if (ka.up8) return !(vel && has_dx) ? 1 : split ? launch_up_h3<true>(ka, ct, s) : launch_up_h3<false>(ka, ct, s);   // all eight parities in one launch
         if (!split) { NBE_VD(launch_h3_v, MODE_FLAT1, 2, false) } else { NBE_VD(launch_h3_v, MODE_FLAT1, 2, true) }
     } else {
         if (!split) { NBE_VD(launch_h3_v, MODE_DOWN, 2, false) } else { NBE_VD(launch_h3_v, MODE_DOWN, 2, true) }
