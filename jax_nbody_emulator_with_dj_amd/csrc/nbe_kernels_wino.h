@@ -19,14 +19,15 @@
 // * One accumulator per output instead of a (main, correction) pair: the weights are scaled by 2^14 (style-modulated
 //   weights are unit vectors per cout, so |U| <= 1) and their lo part is kept UNSCALED (|lo| <= 2^3, exact to 2^-24 of
 //   the largest weight); the product hi(w) * lo(x), which the direct kernel sums in a separate accumulator because lo(x)
-//   is stored times 2^11, takes its 2^-11 on the weight operand (one v_pk_mul_f16 per register, exact for every weight
-//   within 2^-18 of the row's scale, absolute error 2^-25 below that).  All three products of a float32 product then
-//   land in the same float32 accumulator; the epilogue multiplies by 2^-14.
+//   is stored times 2^11, meets an UNSCALED lo part here: the transformed planes are made by this kernel, and their lo part
+//   is written as err + (a lo +- b lo) 2^-11 (NBE_WINO_LOU below; until then the 2^-11 sat on a copy of every weight
+//   operand).  All three products of a float32 product then land in the same float32 accumulator; the epilogue
+//   multiplies by 2^-14.
 //   => 128 accumulator registers hold 64 couts x 32 positions x 2 planes x (y, dy): the wave tile, LDS image and operand
 //   reads per MFMA of conv_h3g_kernel<false, TALL>.
 // * The transformed planes V = a +- b are built by the workgroup itself: each wave loads its share of the two raw
-//   patches into registers (16 B per lane and part), joins hi/lo to float32, adds, splits again and writes the result
-//   into the LDS patch buffer of the NEXT stage in the layout the B operands are read in.  Weights still arrive by
+//   patches into registers (16 B per lane and part), adds them part-wise in packed f16 (TwoSum for the hi parts' rounding
+//   error: xf_step) and writes the result into the LDS patch buffer of the NEXT stage in the layout the B operands are read in.  Weights still arrive by
 //   global -> LDS DMA.  LDS: 2 x 36 KB of weights + 2 x 44 KB of patches, as in conv_h3g_kernel.
 //
 // A stage is (phase, chunk, xi); stage s accumulates into set s & 1.  Per 16 input channels and 512 outputs: 4 stages of
