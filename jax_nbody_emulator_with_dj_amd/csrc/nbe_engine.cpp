@@ -95,6 +95,10 @@ struct Layer {
     const Layer* fskip = nullptr;                 // conv_1: the block's skip layer, when the block can run fused
     const float* b_sub = nullptr;                 // skip: beta of the block's conv_1, folded into dW_s~ when fused
     float* bias_f = nullptr;                      // conv_1: (b_1 + b_s) * act_scale (device, padded like pw.bias)
+    // float16 model: a fused skip exists in the Winograd-z kernel only, and a launch that has no Winograd-z form (an odd number
+    // of planes, NBE_WINO=0) runs the block unfused -- so the skip keeps its tangent weights in both versions: dwn without
+    // conv_1's beta (pw.dw, the skip's own launch) and dwn_f with it folded in (pw.ww, the fused stages)
+    float* dwn_f = nullptr;
 };
 
 // pad > 0: the tensor carries a periodic halo of `pad` voxels in y and x around its interior (periodic-yx mode)
@@ -574,7 +578,9 @@ static const Layer* find_layer(nbe_ctx* c, const char* block, const char* layer)
 // (dst: write the block's result there -- a view with the result's geometry -- instead of allocating it)
 // (has_dx false: conv_l00, whose skip reads the input field -- fused with F_SKIP_NODX)
 // (displacement only: conv_h3w_kernel<SKIP, NOVEL> is the one kernel that runs a fused skip without a tangent)
-static bool block_fused(nbe_ctx* c, const Layer* L1, bool) { return c->fuse && L1->fskip != nullptr && (c->vel || !wino_env_off()); }
+// (the float16 model: as displacement only -- the Winograd-z kernel is the one kernel with a fused skip)
+static bool wino_only_fuse(const nbe_ctx* c) { return !c->vel || c->prec == PREC_F16; }
+static bool block_fused(nbe_ctx* c, const Layer* L1, bool) { return c->fuse && L1->fskip != nullptr && (!wino_only_fuse(c) || !wino_env_off()); }
 
 // hidden tensor of a block whose input x has `pad`: interior (Hi - sy) x (Wi - sy).  A fused block gives it the row
 // and plane pitch of x (conv_h3g_kernel fetches the skip's patches of x with the offsets of its own input's).
@@ -593,7 +599,7 @@ static int resblock(nbe_ctx* c, const char* name, const Tensor& x, bool has_dx, 
     const int sy = pad ? 0 : 2;                                  // what one 3x3x3 convolution takes off y and x
     // (displacement only: the fused skip exists in conv_h3w_kernel alone, which pairs planes -- an odd number of result planes,
     // the 5 planes of conv_c behind a 104-voxel input, takes the unfused path)
-    const bool fused = block_fused(c, L1, has_dx) && (c->vel || (D & 1) == 0);
+    const bool fused = block_fused(c, L1, has_dx) && (!wino_only_fuse(c) || (D & 1) == 0);
     // Unfused: the second convolution adds the skip as a residual and writes its result over it (every lane reads its
     // residual elements before it stores the same elements): one full-resolution tensor pair less at the workspace peak.
     // Fused (gauged f16x3): conv_1 computes the skip itself from x -- no skip launch, no residual round trip.
@@ -1493,7 +1499,7 @@ static void free_layers(nbe_ctx* c) {
         Layer& L = kv.second;
         (void)hipFree(L.weight); (void)hipFree(L.sw); (void)hipFree(L.sb); (void)hipFree(L.wn); (void)hipFree(L.dwn);
         (void)hipFree(L.pw.w); (void)hipFree(L.pw.dw); (void)hipFree(L.pw.bias); (void)hipFree(L.bias0); (void)hipFree(L.pw.stem); (void)hipFree(L.pw.ww); (void)hipFree(L.pwn.w); (void)hipFree(L.pwn.dw); (void)hipFree(L.bias_f);
-        (void)hipFree(L.alpha); (void)hipFree(L.beta);
+        (void)hipFree(L.alpha); (void)hipFree(L.beta); (void)hipFree(L.dwn_f);
     }
     c->layers.clear();
     c->bias_scale = 1.f; c->bias_max = 0.f; c->bias_dirty = true;
@@ -1540,7 +1546,7 @@ static int pack_wino(nbe_ctx* c) {
         if (L.pw.ww && L.kind == 0 && (L.g6 || !c->vel)) launch_pack_h3w(L.wn, L.cout, L.cin, L.pw.cin_pad, L.pw.ctiles, L.pw.ww, c->wino_flag, c->stream, c->prec);
         if (L.pw.ww && L.kind == 1 && (c->vel ? (L.b_sub && c->fuse) : c->novel_fuse)) {   // a fused skip: [W_s | dW_s~] for conv_h3w_kernel<SKIP>
             launch_pack_h3w_skip(L.wn, L.cout, L.cin, L.pw, L.pw.ww, c->wino_flag, c->stream);
-            if (c->vel) launch_pack_h3w_skip(L.dwn, L.cout, L.cin, L.pw, L.pw.ww + L.pw.floats, c->wino_flag, c->stream);
+            if (c->vel) launch_pack_h3w_skip(c->prec == PREC_F16 ? L.dwn_f : L.dwn, L.cout, L.cin, L.pw, L.pw.ww + L.pw.floats, c->wino_flag, c->stream);
         }
     }
     int bad = 0;
@@ -1548,6 +1554,7 @@ static int pack_wino(nbe_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     c->wino_ok = bad == 0;
     if (!c->vel) c->fuse = c->novel_fuse && c->wino_ok;         // displacement only: the fused skips live in the Winograd-z kernel
+    if (c->prec == PREC_F16) c->fuse = c->fuse && c->wino_ok;   // the float16 model: likewise
     return 0;
 }
 
@@ -1615,6 +1622,13 @@ static int wire_gauge(nbe_ctx* c) {
         static const bool no_fuse = getenv("NBE_FUSE") && atoi(getenv("NBE_FUSE")) == 0;        // A/B switch
         if (c->prec == PREC_F16X3 && !no_fuse && (!L1->pwn.w || Ls->pwn.dw) &&
             3 * (L1->pw.cin_pad / 16) + Ls->pw.cin_pad / 16 <= NBE_MAX_GROUPS) {
+            L1->fskip = Ls; Ls->b_sub = L1->beta;
+            const int nb = L1->pw.ctiles * 32 * L1->pw.ni;
+            HIPCHK(hipMalloc((void**)&L1->bias_f, nb * 4));
+        }
+        // float16 model (style path): the skip runs inside conv_h3w_kernel<SKIP, ., F16> wherever conv_1's launch has that form
+        if (c->prec == PREC_F16 && !no_fuse && L1->pw.ww && Ls->pw.ww && Ls->dwn_f && L1->pw.ctiles == Ls->pw.ctiles &&
+            2 * (Ls->pw.cin_pad / 32) <= 16) {                   // NBE_MAX_WSKIP (nbe_kernels_wino.h)
             L1->fskip = Ls; Ls->b_sub = L1->beta;
             const int nb = L1->pw.ctiles * 32 * L1->pw.ni;
             HIPCHK(hipMalloc((void**)&L1->bias_f, nb * 4));
@@ -1784,6 +1798,10 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 4 / 3 * 4));
         if (c->prec == PREC_F16X3 && L.kind == 1 && !L.pwn.w && pw.cin_pad / 16 <= 8)     // a skip that may run fused: W_s and dW_s~
             HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 2 * 4));
+        if (style && L.kind == 1 && !L.first && wino_f16_layer(c->prec, c->vel, pw.cin_pad)) {   // float16 model, style path: the same
+            HIPCHK(hipMalloc((void**)&pw.ww, pw.floats * 2 * 4));
+            HIPCHK(hipMalloc((void**)&L.dwn_f, nw * 4));
+        }
         // the first layer in its own packing (stem_h3_kernel): K = 27 taps x 3 channels = 81 <= 96
         if (c->prec == PREC_F16X3 && c->vel && L.kind == 0 && L.first && d.cin <= 3 && d.cout <= 64)
             HIPCHK(hipMalloc((void**)&pw.stem, 4 * 3 * 4 * 64 * 16));
@@ -1952,14 +1970,17 @@ int nbe_set_cosmology(nbe_ctx* c, float Om, float Dz) {
         // (map order: a block's conv_1, which writes its beta, comes before its skip, which folds it in as b_sub)
         launch_modulate(L.weight, L.sw, L.sb, L.cout, L.cin, L.k * L.k * L.k, s0, s1, c->eps, L.first ? 1 : 0,
                         L.wn, c->vel ? L.dwn : nullptr, c->stream, use_gauge ? L.a_in : nullptr, use_gauge ? L.beta : nullptr,
-                        use_gauge ? L.b_sub : nullptr);
+                        (use_gauge && c->prec != PREC_F16) ? L.b_sub : nullptr);
+        if (use_gauge && c->prec == PREC_F16 && c->vel && L.b_sub && L.dwn_f)     // float16 model: the fused stages' version beside it
+            launch_modulate(L.weight, L.sw, L.sb, L.cout, L.cin, L.k * L.k * L.k, s0, s1, c->eps, L.first ? 1 : 0,
+                            L.wn, L.dwn_f, c->stream, L.a_in, nullptr, L.b_sub);
         launch_pack(L.wn, L.cout, L.cin, L.kind, L.pw, L.pw.w, c->stream);
         if (L.pwn.w) launch_pack(L.wn, L.cout, L.cin, L.kind, L.pwn, L.pwn.w, c->stream);
         if (L.pwn.dw) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pwn, L.pwn.dw, c->stream);
         if (c->vel && !(use_gauge && L.g6)) launch_pack(L.dwn, L.cout, L.cin, L.kind, L.pw, L.pw.dw, c->stream);
     }
     c->gauge_active = use_gauge;
-    c->fuse = use_gauge && c->prec == PREC_F16X3;               // blocks with Layer::fskip run their skip inside conv_1
+    c->fuse = use_gauge && prec_is_half(c->prec);               // blocks with Layer::fskip run their skip inside conv_1
     if (pack_wino(c)) return 1;
     HIPCHK(hipGetLastError());
     c->modulated = true; c->mod_Om = Om; c->mod_Dz = Dz;

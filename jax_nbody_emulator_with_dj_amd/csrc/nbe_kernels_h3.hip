@@ -2189,6 +2189,8 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
     if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split)) {
         if (split && !vel && ka.ww && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1)
             return launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s, true);     // 1: no such form for this launch (an engine bug)
+        if (!split && vel && has_dx && ka.beta && ka.ww && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1)
+            return launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s, false, true);   // the float16 model's Winograd-z form
         return 1;
     }
 #define NBE_VD(F, ...)                                                          \
@@ -2210,7 +2212,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
             if (ka.ww && launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s) == 0) return 0;     // Winograd along z; 1: no such form for this launch
             return tall ? launch_h3g<false, true>(ka, ct, s) : launch_h3g<false, false>(ka, ct, s);
         }
-        if (ka.ww && launch_h3w(ka, ka.ww, nullptr, 0, ct, s, false, true) == 0) return 0;   // float16 model: Winograd along z
+        if (ka.ww && launch_h3w(ka, ka.ww, ka.wws, ka.wws_set_floats, ct, s, false, true) == 0) return 0;   // float16 model: Winograd along z
         return launch_h2q<false, true>(ka, ct, s);
     }
     const bool first_flat = l0_flat && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.nchunk == 1;
@@ -2251,7 +2253,7 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
 __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ w, int cout, int cin, int kind,
                                                       int mode, int nchunk, long halves_per_set, int nsets,
                                                       int parts, int cout_t, _Float16* __restrict__ dst,
-                                                      float wscale = 0.f, int* __restrict__ flag = nullptr) {
+                                                      float wscale = 0.f, int* __restrict__ flag = nullptr, int f16w = 0) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= halves_per_set * nsets) return;
     const int TAPS = mode_taps(mode), nseg = mode_nseg(mode);
@@ -2268,7 +2270,8 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
     const int set = (int)r;
     const int chunk = stage / nseg, seg = stage - chunk * nseg;
     const int h = u / parts, part = u - h * parts;
-    const int ci = chunk * 16 + 8 * h + j;
+    // f16w: conv_h3w_kernel's float16 form -- a chunk is 32 channels, unit u holds channels 8 u .. 8 u + 7 (no lo part)
+    const int ci = f16w ? chunk * 32 + 8 * u + j : chunk * 16 + 8 * h + j;
     const int oc = ct * cout_t + co;
     int k, kz, ky, kx;
     if (kind == 0) { k = 3; kz = seg / 3; ky = seg % 3; kx = tap; }
@@ -2281,7 +2284,7 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
         v *= wscale;
         if (!(fabsf(v) <= 60000.f)) { atomicOr(flag, 1); v = 0.f; }
         const _Float16 h = (_Float16)v;
-        dst[idx] = part == 0 ? h : (_Float16)(v - (float)h);
+        dst[idx] = (part == 0 || f16w) ? h : (_Float16)(v - (float)h);
         return;
     }
     const _Float16 hi = (_Float16)v;
@@ -2291,6 +2294,11 @@ __global__ __launch_bounds__(256) void pack_h3_kernel(const float* __restrict__ 
 // a fused skip's weights for conv_h3w_kernel: the FLAT1 packing of `pw` with the kernel's 2^14 scale (dst: pw.floats floats)
 void launch_pack_h3w_skip(const float* w_oidhw, int cout, int cin, const PackedW& pw, float* dst, int* flag, hipStream_t s) {
     const long halves = pw.floats * 2;
+    if (pw.prec == PREC_F16) {                                   // 32-channel chunks of four units, scale 2^8 (WINO_WSCALE_F16)
+        hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((halves + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
+                           1, pw.mode, pw.cin_pad / 32, halves, 1, 2, pw.cout_t, (_Float16*)dst, 256.0f, flag, 1);
+        return;
+    }
     hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((halves + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
                        1, pw.mode, pw.cin_pad / 16, halves, 1, 2, pw.cout_t, (_Float16*)dst, 16384.0f, flag);
 }

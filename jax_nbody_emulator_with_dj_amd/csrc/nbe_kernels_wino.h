@@ -98,7 +98,7 @@ struct WinoKArgs {
 // skip as computed by its own launch -- the float16 model has no fused skip), rounds once and stores one plane per unit.
 template <bool SKIP, bool NOVEL, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
-    static_assert(!(F16 && (NOVEL || SKIP)), "the float16 form has neither a fused skip nor a displacement-only variant");
+    static_assert(!(F16 && NOVEL), "the float16 form has no displacement-only variant");
     typedef HGGeom<false, true, false> G;
     constexpr int NW = 8, CT = 64, TAPU = G::TAPU, WGU = G::WG, XBASE = G::XBASE, MT = 4, NT = 2, NTILE = 8;
     constexpr int ZROW = G::LDS_UNITS;                           // 64 zeroed units behind the patch buffers (NBE_WINO_ZROW)
@@ -527,6 +527,17 @@ __global__ __launch_bounds__(512, 2) void conv_h3w_kernel(WinoKArgs a) {
         const _Float16 m1 = ks ? kInv : (_Float16)1.0f;
         const int aS = wb + (2 * kh) * CT + c;
         const int bS = xb + (2 * kh + ks) * HQ_PP + rowp * HP_RS + c + SH4;
+        if (F16) {
+            // a chunk of the float16 model's skip is 32 channels, the K halves their two 16-channel halves: three products,
+            // [W_s0 | W_s1] . [x0 | x1] -> Y,  the same . [dx~0 | dx~1] -> DY,  [dW_s~0 | dW_s~1] . [x0 | x1] -> DY
+            const int aF = wb + (2 * kh + ks) * CT + c;
+            LA(a1, aF); LB(bx, bS); LB(bd, bS + HQ_XT); LA(d1, aF + TAPU);
+            NBE_SB; MM8(Y, a1, bx, -1, 0, false); NBE_SB;
+            MM8(DY, a1, bd, -1, 0, false); NBE_SB;
+            MM8(DY, d1, bx, -1, 0, false); NBE_SB;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            return;
+        }
         LA(a1, aS); LB(bx, bS); LA(a2, aS + CT); LB(bd, bS + HQ_XT);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a1[mt] = a1[mt] * m1;
@@ -793,8 +804,10 @@ static int launch_h3w(const ConvKArgs& ka_in, const float* ww, const float* wws,
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     ConvKArgs ka = ka_in;
     if (f16) {                                                   // 16-channel chunks -> 32-channel stages
-        if (novel || ka.nskip > 0 || (ka.nchunk & 1) || (ka.csplit < ka.nchunk && (ka.csplit & 1))) return 1;
+        if (novel || (ka.nchunk & 1) || (ka.csplit < ka.nchunk && (ka.csplit & 1))) return 1;
+        if (ka.nskip > 0 && ((ka.nskip & 1) || (ka.s_csplit < ka.nskip && (ka.s_csplit & 1)) || (ka.flags & F_SKIP_NODX))) return 1;
         ka.nchunk /= 2; if (ka.csplit < (1 << 29)) ka.csplit /= 2;
+        ka.nskip /= 2; if (ka.s_csplit < (1 << 29)) ka.s_csplit /= 2;
     }
     if (!ww || (!f16 && (ka.flags & F_RES)) || (ka.Dv & 1) || 4 * ka.nchunk > NBE_MAX_WSTAGES || (!novel && !ka.beta)) return 1;
     if (ka.nskip > 0 && (!wws || 2 * ka.nskip > NBE_MAX_WSKIP)) return 1;
@@ -808,6 +821,7 @@ static int launch_h3w(const ConvKArgs& ka_in, const float* ww, const float* wws,
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv_h3w_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     WinoKArgs wa;
@@ -860,7 +874,8 @@ static int launch_h3w(const ConvKArgs& ka_in, const float* ww, const float* wws,
             e.xa = x + off; e.xb = e.xa; e.dxd = novel ? rows8 : dx - x; e.w = (const char*)wws + (long)sc * G::TAPU * 16; e.psb = ps * 16; e.sb = 0.f; e.pad_ = 0;
         }
     dim3 grid(wa.ntiles * ctiles, 1, 1), block(512, 1, 1);
-    if (f16) hipLaunchKernelGGL((conv_h3w_kernel<false, false, true>), grid, block, smem, s, wa);
+    if (f16 && ka.nskip > 0) hipLaunchKernelGGL((conv_h3w_kernel<true, false, true>), grid, block, smem, s, wa);
+    else if (f16) hipLaunchKernelGGL((conv_h3w_kernel<false, false, true>), grid, block, smem, s, wa);
     else if (novel) {
         wa.dws_delta = 0;
         if (ka.nskip > 0) hipLaunchKernelGGL((conv_h3w_kernel<true, true>), grid, block, smem, s, wa);

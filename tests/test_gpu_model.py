@@ -224,9 +224,13 @@ def test_float16_mode(engine_factory, small, monkeypatch):
     e.profile_reset(); e.profile_enable(True)
     d, v = e.forward(x, DZ, VF)
     e.profile_enable(False)
-    names = [k["kernel"] for k in e.profile_read()]
+    prof = e.profile_read()
+    names = [k["kernel"] for k in prof]
+    skips = sum(k["launches"] for k in prof if k["kernel"].startswith("conv_h1<FLAT1,vel,dx>"))
     # production width: the gauged 3x3x3 layers run the Winograd-z form (conv_h3w_kernel<., ., F16>) wherever a launch has an
-    # even number of planes; NBE_WINO=0 puts all of them on conv_h2q_kernel -- both within the float16 tolerances
+    # even number of planes, with the block's 1x1x1 skip fused into conv_1 there (conv_l00, whose skip reads three channels,
+    # and a conv_c with an odd number of planes keep theirs as launches of their own); NBE_WINO=0 puts everything on
+    # conv_h2q_kernel and the general 1x1x1 kernel -- both within the float16 tolerances
     assert any(n.startswith("conv_h1w<FLAT3") for n in names), names
     print("f16 mid64: disp rel_l2 %.3e vel rel_l2 %.3e" % (rel_l2(d, gold["net64_disp"]), rel_l2(v, gold["net64_vel"])))
     assert rel_l2(d, gold["net64_disp"]) <= 2e-3 and rel_l2(v, gold["net64_vel"]) <= 4e-2
@@ -236,6 +240,9 @@ def test_float16_mode(engine_factory, small, monkeypatch):
     e.profile_enable(False)
     monkeypatch.delenv("NBE_WINO")
     assert not any(k["kernel"].startswith("conv_h1w") for k in e.profile_read())
+    skips0 = sum(k["launches"] for k in e.profile_read() if k["kernel"].startswith("conv_h1<FLAT1,vel,dx>"))
+    print("f16 mid64: %d skip launches with fusion, %d without" % (skips, skips0))
+    assert skips0 == 9 - 1 and skips <= 2        # (conv_l00's skip has no input tangent: another kernel name)
     print("f16 mid64, direct kernels: disp rel_l2 %.3e vel rel_l2 %.3e; Winograd-z vs direct %.3e / %.3e" % (
         rel_l2(d0_, gold["net64_disp"]), rel_l2(v0_, gold["net64_vel"]), rel_l2(d, d0_), rel_l2(v, v0_)))
     assert rel_l2(d0_, gold["net64_disp"]) <= 2e-3 and rel_l2(v0_, gold["net64_vel"]) <= 4e-2
