@@ -55,11 +55,13 @@ def main():
     assert H.shape == (3, 160, 144, 144) and bool(torch.isfinite(H).all())
     torch.cuda.synchronize()
     brick_protocol_with_itself_as_neighbour(dev)
+    # the float16 model at a width where its Winograd-z form and fused skips apply (Cin a multiple of 32)
+    brick_protocol_with_itself_as_neighbour(dev, precision="f16", mid_chan=32)
     dist.destroy_process_group()
     print("rccl self check: ok")
 
 
-def brick_protocol_with_itself_as_neighbour(dev):
+def brick_protocol_with_itself_as_neighbour(dev, precision="f16x3", mid_chan=8):
     """The whole z-slab brick step of ShardedBox over RCCL -- four face exchanges as grouped P2P on the communication stream,
     events into the engine's stream, the skip-connection planes waited for inside nbe_brick_finish -- with ONE rank that is its
     own z-minus and z-plus neighbour (a rank grid of (2,1,1) whose two ranks are this process: what world_size 2 does, where
@@ -67,8 +69,8 @@ def brick_protocol_with_itself_as_neighbour(dev):
     from jax_nbody_emulator_with_dj_amd.engine import Engine
     from oracle import params as P
     size = (64, 64, 64)
-    eng = Engine(device=0, mid_chan=8, compute_vel=True, precision="f16x3")
-    eng.load_params(P.synthetic_params(seed=61, mid_chan=8), premodulated=False)
+    eng = Engine(device=0, mid_chan=mid_chan, compute_vel=True, precision=precision)
+    eng.load_params(P.synthetic_params(seed=61, mid_chan=mid_chan), premodulated=False)
     Dz, vf = 0.7731811501855036, 50.537651303131064
     eng.set_cosmology(0.3, Dz)
     box = torch.randn((3,) + size, device=dev)
@@ -86,8 +88,8 @@ def brick_protocol_with_itself_as_neighbour(dev):
         sharding.coords_rank = keep
     torch.cuda.synchronize()
     ed, ev = float((disp - d_ref).abs().max()), float((vel - v_ref).abs().max())
-    print("brick protocol over RCCL, own neighbour: max|delta| disp %.3g vel %.3g (bit-identical: %s)"
-          % (ed, ev, bool(torch.equal(disp, d_ref) and torch.equal(vel, v_ref))))
+    print("brick protocol over RCCL, own neighbour, %s mid_chan %d: max|delta| disp %.3g vel %.3g (bit-identical: %s)"
+          % (precision, mid_chan, ed, ev, bool(torch.equal(disp, d_ref) and torch.equal(vel, v_ref))))
     assert torch.equal(disp, d_ref) and torch.equal(vel, v_ref)
     eng.close()
 
