@@ -117,6 +117,39 @@ def test_process_box_float16_model():
     assert rel_l2(dis, dis0) <= 1e-3 and rel_l2(vel, vel0) <= 1e-2
 
 
+def test_process_box_float16_model_on_its_winograd_and_fused_kernels(monkeypatch):
+    """The float16 model at a width where conv_h3w_kernel<SKIP, ., F16> applies (Cin a multiple of 32): the default plan (merged
+    periodic tile, z-slabs where the planner takes them) with the Winograd-z form, fused skips and the one-launch up-sampling
+    against the caller's own grid on the direct kernels with every skip as a launch of its own (NBE_WINO=0: conv_h2q_kernel,
+    which the layer tests hold to the float64 oracle).  A schedule or wiring error in the new path is an O(1) difference; the
+    arithmetic's own is one float16 rounding per layer."""
+    from jax_nbody_emulator_with_dj_amd import models
+    mid, size, ndiv = 32, (96, 64, 64), (3, 2, 2)
+    p = _synthetic(17, mid)
+    box = np.random.default_rng(18).standard_normal((3,) + size).astype(np.float32)
+    cfg = J.SubboxConfig(size=size, ndiv=ndiv, dtype=np.float16)
+    emu = J.create_emulator(load_params=False, processor_config=cfg, mid_chan=mid)
+    emu.processor.params = p
+    eng = models.get_engine(emu.model, None, "f16")
+    eng.profile_reset(); eng.profile_enable(True)
+    dis, vel = emu.process_box(box, Z, OM, show_progress=False)
+    eng.profile_enable(False)
+    names = [k["kernel"] for k in eng.profile_read()]
+    assert any(n.startswith("conv_h1w<FLAT3") for n in names) and any(n.startswith("up_h3<8 parities") for n in names), names
+    monkeypatch.setenv("NBE_WINO", "0")
+    eng.set_max_tile(0)
+    try:
+        eng.profile_reset(); eng.profile_enable(True)
+        dis0, vel0 = emu.process_box(box, Z, OM, show_progress=False)
+        eng.profile_enable(False)
+    finally:
+        eng.set_max_tile(512)
+    assert not any(k["kernel"].startswith("conv_h1w") for k in eng.profile_read())
+    e = rel_l2(dis, dis0), rel_l2(vel, vel0)
+    print("process_box f16 mid 32, default plan and kernels vs caller's grid on the direct kernels: disp %.3e vel %.3e" % e)
+    assert np.all(np.isfinite(dis)) and np.all(np.isfinite(vel)) and e[0] <= 2e-3 and e[1] <= 4e-2
+
+
 def test_trailing_voxels_stay_zero():
     """size % ndiv != 0: crop_size floors and the remainder is never written (subbox.py:49, :168-170)."""
     p = _synthetic(3, 8)
