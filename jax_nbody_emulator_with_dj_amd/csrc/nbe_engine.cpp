@@ -494,7 +494,7 @@ static void prof_collect(nbe_ctx* c) {
 }
 
 static std::string conv_name(const PackedW& pw, bool vel, bool has_dx, bool g6 = false, bool up8 = false) {
-    if (up8) return "up_h3<8 parities,vel,dx>";
+    if (up8) return vel ? "up_h3<8 parities,vel,dx>" : "up_h3<8 parities,novel>";
     const char* m = pw.mode == MODE_FLAT3 ? "FLAT3" : pw.mode == MODE_FLAT1 ? "FLAT1" : "DOWN";
     const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);
     if (stem_on && pw.stem && vel && !has_dx && pw.mode == MODE_FLAT3) return "stem_h3<FLAT3,vel,nodx>";
@@ -711,9 +711,9 @@ static int upblock(nbe_ctx* c, const char* name, const Tensor& x, const Tensor& 
     const int Hx = x.p.H - 2 * xcrop, Wx = x.p.W - 2 * xcrop;
     if (cat.p.D != 2 * x.p.D || cat.p.H - 2 * cat.pad != 2 * Hx || cat.p.W - 2 * cat.pad != 2 * Wx)
         return fail("internal: concat geometry mismatch in %s", name);
-    // f16x3 with velocity and Cin <= 64: all eight parities in one launch (up_h3_kernel: the input is read once)
+    // f16-based arithmetic and Cin <= 64: all eight parities in one launch (up_h3_kernel: the input is read once)
     const bool up8_off = getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0;                 // A/B switch
-    const bool up8 = prec_is_half(c->prec) && c->vel && L->pw.cin_pad <= 64 && !up8_off;
+    const bool up8 = prec_is_half(c->prec) && L->pw.cin_pad <= 64 && !up8_off;
     const int out_g0 = g0 >= 0 ? g0 : c->mid / (c->prec == PREC_F16 ? 8 : 4);
     for (int p = 0; p < (up8 ? 1 : 8); ++p) {
         ConvLaunch cl; cl.in = x.p; cl.in_off = ((int64_t)xcrop * x.p.W + xcrop);
@@ -2896,7 +2896,7 @@ static int test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x,
         else if (kind == 2) { cl.Dv = OD; cl.Hv = OH; cl.Wv = OW; rc = run_conv(c, L, cl, has_dx); }
         else {
             // as upblock(): one launch for all eight parities where up_h3_kernel applies
-            const bool up8 = prec_is_half(c->prec) && vel && has_dx && pw.cin_pad <= 64 && !(getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0);
+            const bool up8 = prec_is_half(c->prec) && (!vel || has_dx) && pw.cin_pad <= 64 && !(getenv("NBE_UP8") && atoi(getenv("NBE_UP8")) == 0);
             for (int p = 0; p < (up8 ? 1 : 8) && !rc; ++p) {
                 ConvLaunch u = cl; u.Dv = D; u.Hv = H; u.Wv = W; u.osz = 2; u.oz = (p >> 2) & 1; u.oy = (p >> 1) & 1; u.ox = p & 1;
                 u.set = up8 ? -1 : p;

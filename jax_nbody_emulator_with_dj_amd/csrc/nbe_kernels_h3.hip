@@ -403,7 +403,8 @@ template <bool SPLIT> struct UpGeom {
     static constexpr int LDS_UNITS = WBASE + 2 * WS;     // f16x3: 10240 units = 163,840 B, all of the CU's LDS; float16: half
 };
 
-template <bool SPLIT>
+// VEL = false: the displacement-only models (no tangent tensors, no dW): the same stages with the primal's products only.
+template <bool SPLIT, bool VEL = true>
 __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     constexpr int UN = UpGeom<SPLIT>::UN, UP_XC = UpGeom<SPLIT>::XC, UP_WS = UpGeom<SPLIT>::WS, UP_WBASE = UpGeom<SPLIT>::WBASE;
     constexpr int PS = SPLIT ? 2 : 1;                        // planes per channel half: hi, lo | one
@@ -424,8 +425,8 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     // 32 wave-instructions per chunk, 4 per wave
     for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-        for (int k = 0; k < UN; ++k) {
-            const int n = wave + 8 * k;                       // 0..8 UN - 1: tensor, unit, quarter (n & 3)
+        for (int k = 0; k < (VEL ? UN : UN / 2); ++k) {
+            const int n = wave + 8 * k;                       // 0..8 UN - 1: tensor, unit, quarter (n & 3)  (!VEL: X only)
             const int t = n / (4 * UN), u = (n >> 2) % UN, qd = n & 3;
             const long v = q0 + a.in_off + qd * 64 + lane;
             const char* src = (const char*)(t ? a.dx : a.x) + (((long)c * UN + u) * a.in_pstride + v) * 16;
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
         for (int k = 0; k < UN / 2; ++k) {
             const int n = wave + 8 * k;                       // 0..4 UN - 1: parity, set (W | dW), unit
             const int par = n / (2 * UN), d = (n / UN) & 1, m = n % UN;
+            if (!VEL && d) continue;                          // (no dW: its rows of the stage stay unused)
             const char* src = (const char*)(d ? a.dw : a.w) + (long)(2 * pp + par) * a.set_stride +
                               (((long)ct * nchunk + c) * (UN * 64) + m * 64 + lane) * 16;
             dma16((const float*)src, lds + UP_WBASE + (st & 1) * UP_WS + n * 64);
@@ -463,23 +465,30 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
         const half8* wb = L8 + UP_WBASE + (st & 1) * UP_WS;
         const half8* xb = L8 + c * UP_XC;
         const int xo = (PS * lh) * UP_XV + half * 128 + jq * 32 + li;
-        const half8 xh = xb[xo], dxh = xb[UN * UP_XV + xo];
-        half8 xl = xh, dxl = dxh;
-        if (SPLIT) { xl = xb[xo + UP_XV]; dxl = xb[UN * UP_XV + xo + UP_XV]; }
+        const half8 xh = xb[xo];
+        half8 dxh = xh, xl = xh, dxl = xh;
+        if (VEL) dxh = xb[UN * UP_XV + xo];
+        if (SPLIT) { xl = xb[xo + UP_XV]; if (VEL) dxl = xb[UN * UP_XV + xo + UP_XV]; }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {                      // x parity jt: its own weights, the same activations
             const int wo = jt * (2 * UN * 64) + (PS * lh) * 64 + 32 * it + li;
-            const half8 wh = wb[wo], dwh = wb[UN * 64 + wo];
+            const half8 wh = wb[wo];
+            half8 dwh = wh;
+            if (VEL) dwh = wb[UN * 64 + wo];
             if (!SPLIT) {                                    // float16: y += w.x, dy += dw.x + w.dx
                 ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
-                dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xh, dm[jt], 0, 0, 0);
-                dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxh, dm[jt], 0, 0, 0);
+                if (VEL) {
+                    dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xh, dm[jt], 0, 0, 0);
+                    dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, dxh, dm[jt], 0, 0, 0);
+                }
                 continue;
             }
-            const half8 wl = wb[wo + 64], dwl = wb[UN * 64 + wo + 64];
+            const half8 wl = wb[wo + 64];
             ym[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, ym[jt], 0, 0, 0);
             yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, yc[jt], 0, 0, 0);
             yc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, yc[jt], 0, 0, 0);
+            if (!VEL) continue;
+            const half8 dwl = wb[UN * 64 + wo + 64];
             dm[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xh, dm[jt], 0, 0, 0);
             dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwh, xl, dc[jt], 0, 0, 0);
             dc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dwl, xh, dc[jt], 0, 0, 0);
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
             const long o0 = okq ? ((long)(2 * z + (pp >> 1)) * a.Ho + (2 * yy + (pp & 1))) * a.Wo + 2 * xx : 0;
             const long o[2] = {o0, o0 + (okq ? 1 : 0)};
             const bool ok[2] = {okq, okq};
-            h3_store2<true, SPLIT>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
+            h3_store2<VEL, SPLIT>(a, ct, it, lh, o, ok, ym, yc, dm, dc);
             zero_acc();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
@@ -509,18 +518,18 @@ __global__ __launch_bounds__(512, 2) void up_h3_kernel(ConvKArgs a) {
     }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, bool VEL = true>
 static int launch_up_h3(ConvKArgs ka, int ctiles, hipStream_t s) {
     constexpr size_t smem = (size_t)UpGeom<SPLIT>::LDS_UNITS * 16;
     static_assert(smem <= 160 * 1024, "LDS budget of one CU");
     if (ka.nchunk > UP_MAXCH) return 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)up_h3_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)up_h3_kernel<SPLIT, VEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     dim3 grid(ka.ntiles, ctiles, 1), block(512, 1, 1);
-    hipLaunchKernelGGL(up_h3_kernel<SPLIT>, grid, block, smem, s, ka);
+    hipLaunchKernelGGL((up_h3_kernel<SPLIT, VEL>), grid, block, smem, s, ka);
     return 0;
 }
 
@@ -2238,7 +2247,11 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
         return 1;
 #endif
     } else if (pw.mode == MODE_FLAT1) {
-        if (ka.up8) return !(vel && has_dx) ? 1 : split ? launch_up_h3<true>(ka, ct, s) : launch_up_h3<false>(ka, ct, s);   // all eight parities in one launch
+        if (ka.up8) {                                            // all eight parities in one launch
+            if (vel && has_dx) return split ? launch_up_h3<true>(ka, ct, s) : launch_up_h3<false>(ka, ct, s);
+            if (!vel) return split ? launch_up_h3<true, false>(ka, ct, s) : launch_up_h3<false, false>(ka, ct, s);
+            return 1;
+        }
         if (!split) { NBE_VD(launch_h3_v, MODE_FLAT1, 2, false) } else { NBE_VD(launch_h3_v, MODE_FLAT1, 2, true) }
     } else {
         if (!split) { NBE_VD(launch_h3_v, MODE_DOWN, 2, false) } else { NBE_VD(launch_h3_v, MODE_DOWN, 2, true) }
