@@ -1984,6 +1984,8 @@ constexpr int ST_WU = 4 * 3 * 4 * 64;                        // weight units: [s
 constexpr int ST_VEC = ST_WU * 4 + ST_PATCH;                  // floats: after the two patch buffers, bias[64] and gout[64]
 constexpr size_t ST_LDS = (size_t)ST_WU * 16 + 2 * ST_PATCH * 2 + 2 * 64 * 4;   // 77,760 B: two workgroups per CU
 
+// VEL = false: the displacement-only models' first layer (the W sets only, y only: half the MFMAs and half the stores).
+template <bool VEL>
 __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
     f32x4* lds = lds_h3;
     const half8* L8 = (const half8*)lds_h3;
@@ -1992,9 +1994,12 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4, kh = q & 1, ks = q >> 1;
 
-    // weights: 48 wave-instructions of 1 KB, 12 per wave
+    // weights: 48 wave-instructions of 1 KB, 12 per wave (displacement only: the first 24, the W sets)
 #pragma unroll
-    for (int k = 0; k < 12; ++k) dma16(a.stem_w + ((long)(wave * 12 + k) * 64 + lane) * 4, lds + (wave * 12 + k) * 64);
+    for (int k = 0; k < (VEL ? 12 : 6); ++k) {
+        const int n = wave * (VEL ? 12 : 6) + k;
+        dma16(a.stem_w + ((long)n * 64 + lane) * 4, lds + n * 64);
+    }
 
     // this lane's B-operand gather: element j of k-step s is k = 32 s + 8 q + j = 3 tap + channel
     int off[3][8];
@@ -2087,8 +2092,10 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
             };
             LA(0); MM(yc, xl); MM(ym, xh);                        // W hi
             LA(1); MM(yc, xh);                                    // W lo
-            LA(2); MM(dc, xl); MM(dm, xh);                        // dW hi
-            LA(3); MM(dc, xh);                                    // dW lo
+            if (VEL) {
+                LA(2); MM(dc, xl); MM(dm, xh);                    // dW hi
+                LA(3); MM(dc, xh);                                // dW lo
+            }
         }
 
         // epilogue: lane (c, q) holds couts 16 mt + 4 q + e of position (row wave, col 16 nt + c)
@@ -2136,15 +2143,18 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
                     split4(v, hi, lo);
                     *(half4*)((char*)a.y + ob) = hi;
                     *(half4*)((char*)a.y + ol) = lo;
-                    split4(dv, hi, lo);
-                    *(half4*)((char*)a.dy + ob) = hi;
-                    *(half4*)((char*)a.dy + ol) = lo;
+                    if (VEL) {
+                        split4(dv, hi, lo);
+                        *(half4*)((char*)a.dy + ob) = hi;
+                        *(half4*)((char*)a.dy + ol) = lo;
+                    }
                 }
             }
         }
     }
 }
 
+template <bool VEL>
 static int launch_stem(ConvKArgs ka, hipStream_t s) {
     ka.tny = (ka.Hv + ST_ROWS - 1) / ST_ROWS;
     ka.tnx = (ka.Wv + ST_COLS - 1) / ST_COLS;
@@ -2155,10 +2165,10 @@ static int launch_stem(ConvKArgs ka, hipStream_t s) {
     static_assert(2 * ST_LDS <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)stem_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS);
+        (void)hipFuncSetAttribute((const void*)stem_h3_kernel<VEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL(stem_h3_kernel, dim3(grid), dim3(256), ST_LDS, s, ka);
+    hipLaunchKernelGGL(stem_h3_kernel<VEL>, dim3(grid), dim3(256), ST_LDS, s, ka);
     return 0;
 }
 
@@ -2191,9 +2201,9 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
 #endif
     const bool split = pw.prec == PREC_F16X3;
     const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);   // A/B switch, default on (read per launch: tests flip it)
-    if (stem_on && ka.stem_w && split && vel && !has_dx && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
+    if (stem_on && ka.stem_w && split && !(vel && has_dx) && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
         !(ka.flags & F_RES) && ka.nskip == 0 && !ka.beta)
-        return launch_stem(ka, s);
+        return vel ? launch_stem<true>(ka, s) : launch_stem<false>(ka, s);
     // a second input segment / a fused skip exist only in the wide gauged f16x3 kernel and in conv_h3w_kernel's displacement-only form
     if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split)) {
         if (split && !vel && ka.ww && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1)
