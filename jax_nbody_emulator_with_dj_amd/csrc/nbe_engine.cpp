@@ -1803,7 +1803,7 @@ static int load_weights(nbe_ctx* c, const nbe_layer_desc* descs, int n, bool sty
             HIPCHK(hipMalloc((void**)&L.dwn_f, nw * 4));
         }
         // the first layer in its own packing (stem_h3_kernel): K = 27 taps x 3 channels = 81 <= 96
-        if (c->prec == PREC_F16X3 && L.kind == 0 && L.first && d.cin <= 3 && d.cout <= 64)
+        if (prec_is_half(c->prec) && L.kind == 0 && L.first && d.cin <= 3 && d.cout <= 64)
             HIPCHK(hipMalloc((void**)&pw.stem, 4 * 3 * 4 * 64 * 16));
         HIPCHK(hipMalloc((void**)&L.bias0, nb * 4));
         HIPCHK(hipMemcpy(L.bias0, pw.bias, nb * 4, hipMemcpyDeviceToDevice));
@@ -2814,7 +2814,7 @@ static int test_layer(nbe_ctx* c, int kind, int crop, int flags, const float* x,
 #define TCHK(e) if ((e) != hipSuccess) { rc = fail("hip error in nbe_test_layer: %s", hipGetErrorString(hipGetLastError())); break; }
         TCHK(hipMalloc((void**)&pw.w, pw.floats * pw.nsets * 4));
         if (vel) TCHK(hipMalloc((void**)&pw.dw, pw.floats * pw.nsets * 4));
-        if (c->prec == PREC_F16X3 && kind == 0 && !has_dx && cin <= 3 && cout <= 64)     // as conv_l00/conv_0: stem_h3_kernel
+        if (prec_is_half(c->prec) && kind == 0 && !has_dx && cin <= 3 && cout <= 64)     // as conv_l00/conv_0: stem_h3_kernel
             TCHK(hipMalloc((void**)&pw.stem, 4 * 3 * 4 * 64 * 16));
         const int nb = pw.ctiles * 32 * pw.ni;
         TCHK(hipMalloc((void**)&pw.bias, nb * 4)); TCHK(hipMemset(pw.bias, 0, nb * 4));

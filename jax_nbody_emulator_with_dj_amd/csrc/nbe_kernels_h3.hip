@@ -1985,8 +1985,10 @@ constexpr int ST_VEC = ST_WU * 4 + ST_PATCH;                  // floats: after t
 constexpr size_t ST_LDS = (size_t)ST_WU * 16 + 2 * ST_PATCH * 2 + 2 * 64 * 4;   // 77,760 B: two workgroups per CU
 
 // VEL = false: the displacement-only models' first layer (the W sets only, y only: half the MFMAs and half the stores).
-template <bool VEL>
+// SPLIT = false: the float16 model (one part: sets [W | dW], three input planes per patch, one MFMA per product and k-step).
+template <bool VEL, bool SPLIT = true>
 __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
+    constexpr int NSETW = (SPLIT ? 2 : 1) * (VEL ? 2 : 1) * 6;   // weight DMA wave-instructions per wave (6 per set over four waves)
     f32x4* lds = lds_h3;
     const half8* L8 = (const half8*)lds_h3;
     _Float16* P = (_Float16*)(lds_h3 + ST_WU);
@@ -1996,8 +1998,8 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 
     // weights: 48 wave-instructions of 1 KB, 12 per wave (displacement only: the first 24, the W sets)
 #pragma unroll
-    for (int k = 0; k < (VEL ? 12 : 6); ++k) {
-        const int n = wave * (VEL ? 12 : 6) + k;
+    for (int k = 0; k < NSETW / 2; ++k) {
+        const int n = wave * (NSETW / 2) + k;
         dma16(a.stem_w + ((long)n * 64 + lane) * 4, lds + n * 64);
     }
 
@@ -2030,7 +2032,7 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
             const int yy = min(ty * ST_ROWS + prow[i], a.H - 1), xx = min(tx * ST_COLS + pcol[i], a.W - 1);
             const long v = ((long)(z + pdz[i]) * a.H + yy) * a.W + xx;
             ph[i] = *(const half4*)(a.x + v * 4);
-            pl[i] = *(const half4*)(a.x + (a.in_pstride + v) * 4);
+            if (SPLIT) pl[i] = *(const half4*)(a.x + (a.in_pstride + v) * 4);
         }
     };
     auto stage = [&](int buf) {                                  // registers -> LDS planes [part][channel][dz][row][col]
@@ -2042,7 +2044,7 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     Pb[ch * ST_PV + pv] = ph[i][ch];
-                    Pb[(3 + ch) * ST_PV + pv] = pl[i][ch];
+                    if (SPLIT) Pb[(3 + ch) * ST_PV + pv] = pl[i][ch];
                 }
             }
         }
@@ -2080,7 +2082,7 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     xh[nt][j] = Pb[off[s][j] + 16 * nt];
-                    xl[nt][j] = Pb[off[s][j] + 16 * nt + 3 * ST_PV];
+                    if (SPLIT) xl[nt][j] = Pb[off[s][j] + 16 * nt + 3 * ST_PV];
                 }
             auto LA = [&](int set) {
 #pragma unroll
@@ -2090,6 +2092,11 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t >> 1], B[t & 1], acc[t], 0, 0, 0);
             };
+            if (!SPLIT) {                                         // float16 model: sets W, dW
+                LA(0); MM(ym, xh);
+                if (VEL) { LA(1); MM(dm, xh); }
+                continue;
+            }
             LA(0); MM(yc, xl); MM(ym, xh);                        // W hi
             LA(1); MM(yc, xh);                                    // W lo
             if (VEL) {
@@ -2122,8 +2129,8 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
                 f32x4 v, dv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = ym[t][e] + yc[t][e] * H3_INV + bv[e];
-                    dv[e] = dm[t][e] + dc[t][e] * H3_INV;
+                    v[e] = ym[t][e] + (SPLIT ? yc[t][e] * H3_INV : 0.f) + bv[e];
+                    dv[e] = dm[t][e] + (SPLIT ? dc[t][e] * H3_INV : 0.f);
                 }
                 if (act) {
 #pragma unroll
@@ -2136,6 +2143,20 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dv[e] += gv[e] * v[e];
                 }
+                if (!SPLIT) {                                    // one f16 plane per unit
+                    if (uok && ook[nt]) {
+                        const long ob = ((long)(a.out_g0 + unit) * a.out_pstride + o[nt]) * 16 + 8 * kh;
+                        half4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (_Float16)v[e];
+                        *(half4*)((char*)a.y + ob) = h;
+                        if (VEL) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = (_Float16)dv[e];
+                            *(half4*)((char*)a.dy + ob) = h;
+                        }
+                    }
+                } else
                 if (uok && ook[nt]) {
                     const long ob = ((long)(a.out_g0 + 2 * unit) * a.out_pstride + o[nt]) * 16 + 8 * kh;
                     const long ol = ob + a.out_pstride * 16;
@@ -2154,7 +2175,7 @@ __global__ __launch_bounds__(256, 2) void stem_h3_kernel(ConvKArgs a) {
     }
 }
 
-template <bool VEL>
+template <bool VEL, bool SPLIT = true>
 static int launch_stem(ConvKArgs ka, hipStream_t s) {
     ka.tny = (ka.Hv + ST_ROWS - 1) / ST_ROWS;
     ka.tnx = (ka.Wv + ST_COLS - 1) / ST_COLS;
@@ -2165,17 +2186,17 @@ static int launch_stem(ConvKArgs ka, hipStream_t s) {
     static_assert(2 * ST_LDS <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)stem_h3_kernel<VEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS);
+        (void)hipFuncSetAttribute((const void*)stem_h3_kernel<VEL, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL(stem_h3_kernel<VEL>, dim3(grid), dim3(256), ST_LDS, s, ka);
+    hipLaunchKernelGGL((stem_h3_kernel<VEL, SPLIT>), dim3(grid), dim3(256), ST_LDS, s, ka);
     return 0;
 }
 
 // stem_w: [set: W hi, W lo, dW hi, dW lo][k-step 3][k-block 4][cout 64][j 8], k = 32 s + 8 q + j = 3 tap + channel
-__global__ __launch_bounds__(256) void pack_stem_kernel(const float* __restrict__ w, int cout, int cin, _Float16* __restrict__ dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over [part 2][s 3][q 4][co 64][j 8]
-    if (idx >= 2 * 3 * 4 * 64 * 8) return;
+__global__ __launch_bounds__(256) void pack_stem_kernel(const float* __restrict__ w, int cout, int cin, _Float16* __restrict__ dst, int parts) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over [part 2 (float16 model: 1)][s 3][q 4][co 64][j 8]
+    if (idx >= parts * 3 * 4 * 64 * 8) return;
     const int j = idx & 7, co = (idx >> 3) & 63, qq = (idx >> 9) & 3, sp = idx >> 11, st = sp % 3, part = sp / 3;
     const int k = 32 * st + 8 * qq + j, tap = k / 3, ch = k - 3 * tap;
     float v = 0.f;
@@ -2201,9 +2222,11 @@ int launch_conv_h3(const PackedW& pw, const ConvKArgs& ka, bool vel, bool has_dx
 #endif
     const bool split = pw.prec == PREC_F16X3;
     const bool stem_on = !(getenv("NBE_STEM") && atoi(getenv("NBE_STEM")) == 0);   // A/B switch, default on (read per launch: tests flip it)
-    if (stem_on && ka.stem_w && split && !(vel && has_dx) && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
-        !(ka.flags & F_RES) && ka.nskip == 0 && !ka.beta)
-        return vel ? launch_stem<true>(ka, s) : launch_stem<false>(ka, s);
+    if (stem_on && ka.stem_w && !(vel && has_dx) && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1 &&
+        !(ka.flags & F_RES) && ka.nskip == 0 && !ka.beta) {
+        if (split) return vel ? launch_stem<true>(ka, s) : launch_stem<false>(ka, s);
+        return vel ? launch_stem<true, false>(ka, s) : launch_stem<false, false>(ka, s);
+    }
     // a second input segment / a fused skip exist only in the wide gauged f16x3 kernel and in conv_h3w_kernel's displacement-only form
     if ((ka.nskip > 0 || ka.csplit < ka.nchunk) && !(ka.beta && split)) {
         if (split && !vel && ka.ww && pw.mode == MODE_FLAT3 && ka.in_off == 0 && ka.osz == 1)
@@ -2327,9 +2350,11 @@ void launch_pack_h3w_skip(const float* w_oidhw, int cout, int cin, const PackedW
 }
 
 void launch_pack_h3(const float* w_oidhw, int cout, int cin, int kind, const PackedW& pw, float* dst, hipStream_t s) {
-    if (pw.stem && kind == 0 && (dst == pw.w || dst == pw.dw))      // the first layer's own format beside the general one
+    if (pw.stem && kind == 0 && (dst == pw.w || dst == pw.dw)) {    // the first layer's own format beside the general one
+        const int parts = pw.prec == PREC_F16X3 ? 2 : 1;
         hipLaunchKernelGGL(pack_stem_kernel, dim3(48), dim3(256), 0, s, w_oidhw, cout, cin,
-                           (_Float16*)pw.stem + (dst == pw.dw ? 2 * 3 * 4 * 64 * 8 : 0));
+                           (_Float16*)pw.stem + (dst == pw.dw ? parts * 3 * 4 * 64 * 8 : 0), parts);
+    }
     const long halves = pw.floats * 2;
     const long total = halves * pw.nsets;
     hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_oidhw, cout, cin,
