@@ -83,3 +83,20 @@ def test_unscaled_lo_part_of_the_transformed_planes():
     xi = rng.integers(-8, 9, size=(16, 6, 5, 7)).astype(np.float64) * 64.0
     wi = rng.integers(-4, 5, size=(8, 16, 3, 3, 3)).astype(np.float64) / 64.0
     assert np.array_equal(W.conv_winograd_z(xi, wi, S=2.0 ** 6, unscaled_lo=True), W.conv_exact(xi, wi))
+
+
+def test_float16_model_winograd_form_rounds_its_operands_once_more():
+    """conv_h3w_kernel<., ., F16> (the float16 model): on the SAME f16 operands a direct evaluation is left with the store's
+    one rounding (2^-12 / sqrt 3 = 1.4e-4 .. 2.1e-4 relative L2), the Winograd-z form also rounds the transformed weights
+    U_xi and the transformed planes V = a +- b to f16: about twice that -- the 7e-4 / 7e-3 of tests/test_gpu_layers.py
+    (measured on the GPU: 4.6e-4 against 2.1e-4)."""
+    x, w = _case(32, 16, (6, 7, 9), 7)
+    x16, w16 = W.f16(x), W.f16(w)
+    ye = W.conv_exact(x16, w16)
+    e_d, e_w = W.rel(W.f16(ye), ye), W.rel(W.f16(W.conv_winograd_z_f16(x16, w16)), ye)
+    assert 1.0e-4 <= e_d <= 2.5e-4 and e_d < e_w <= 6e-4, (e_d, e_w)
+    # exact arithmetic: 32-channel stages, two-phase order, negated U3 -- still the convolution
+    rng = np.random.default_rng(8)
+    xi = rng.integers(-8, 9, size=(32, 6, 5, 7)).astype(np.float64)
+    wi = rng.integers(-4, 5, size=(8, 32, 3, 3, 3)).astype(np.float64) / 64.0
+    assert np.array_equal(W.conv_winograd_z_f16(xi, wi), W.conv_exact(xi, wi))

@@ -103,6 +103,35 @@ def conv_winograd_z(x, w, S=2.0 ** 14, transform='f16', unscaled_lo=False):
     return y
 
 
+def conv_winograd_z_f16(x, w, S=256.0):
+    """The float16 model's form (conv_h3w_kernel<., ., F16>): operands are plain f16 numbers (x as stored, w as given), the
+    transformed weights U_xi * 2^8 and the transformed planes V = a +- b are each rounded to f16 once more, float32 accumulation
+    per 32-channel tap-pair product, same two-phase K order.  Returns float32-rounded outputs BEFORE the store's f16 rounding."""
+    cout, cin = w.shape[:2]
+    D, H, W = x.shape[1:]
+    Do, Ho, Wo = D - 2, H - 2, W - 2
+    assert Do % 2 == 0 and cin % 32 == 0
+    U = f16(np.stack([w[:, :, 0], (w[:, :, 0] + w[:, :, 1] + w[:, :, 2]) / 2, (w[:, :, 0] - w[:, :, 1] + w[:, :, 2]) / 2,
+                      -w[:, :, 2]], axis=0) * S)
+    PA, PB, SB = (0, 1, 2, 1), (2, 2, 1, 3), (-1.0, 1.0, -1.0, -1.0)
+    y = np.zeros((cout, Do, Ho, Wo))
+    for p in range(Do // 2):
+        def run(acc, xi):
+            V = f16(x[:, 2 * p + PA[xi]] + SB[xi] * x[:, 2 * p + PB[xi]])
+            for c0 in range(0, cin, 32):
+                for dy in range(3):
+                    for dx in range(3):
+                        sl = (slice(c0, c0 + 32), slice(dy, dy + Ho), slice(dx, dx + Wo))
+                        acc = f32(acc + np.einsum('oi,iyx->oyx', U[xi][:, c0:c0 + 32, dy, dx], V[sl]))
+            return acc
+        A = run(np.zeros((cout, Ho, Wo)), 1)
+        B = run(np.zeros((cout, Ho, Wo)), 2)
+        A, B = f32(A + B), f32(A - B)
+        A, B = run(A, 0), run(B, 3)
+        y[:, 2 * p], y[:, 2 * p + 1] = f32(A / S), f32(B / S)
+    return y
+
+
 def unit_rows(w):
     return w / np.sqrt((w ** 2).sum(axis=(1, 2, 3, 4), keepdims=True))
 
@@ -123,6 +152,10 @@ if __name__ == "__main__":
     for s in (1e-3, 30.0, 1e3):
         xs = f32(x * s)
         print("  input scale %g: %.2e" % (s, rel(conv_winograd_z(xs, w), conv_exact(xs, w))))
+    x16, w16 = f16(x), f16(w)                                      # the float16 model: operands as the engine stores them
+    y16 = conv_exact(x16, w16)
+    print("float16 model on the same f16 operands, after the store's f16 rounding: direct %.2e, Winograd-z form %.2e"
+          % (rel(f16(y16), y16), rel(f16(conv_winograd_z_f16(x16, w16)), y16)))
     print("unscaled lo part of V (default build), activation RMS as the range shift leaves it:")
     for s in (2.0 ** 6, 8.0, 1.0, 2.0 ** -3, 2.0 ** -6):
         xs = f32(x * s)
