@@ -63,6 +63,29 @@ def test_apply_matches_golden(tag, precision):
     _close(d4[0], GOLD[tag + "_disp"], 2e-5, 2e-4, tag + " premod novel disp")
 
 
+def test_apply_follows_the_dtype_of_x():
+    """The arithmetic follows x's dtype as in the reference (style_layers_vel.py:103-105, tests/test_style_nbody_emulator_vel_core.py:
+    303-335): float16 -> the float16 engine, bfloat16 (a torch tensor: NumPy has no such type) -> rounded in, computed at the
+    float32-equivalent arithmetic, rounded out -- at least the accuracy asked for; outputs come back in x's dtype, on x's device."""
+    import torch
+    tag = "net8"
+    seed_p, seed_x, mid, d0, d1, d2 = (int(v) for v in GOLD[tag + "_meta"])
+    p = _synthetic(seed_p, mid)
+    x = np.random.default_rng(seed_x).standard_normal((1, 3, d0, d1, d2)).astype(np.float32)
+    Dz, vf = J.growth_factor(Z, OM), J.vel_norm(Z, OM)
+    model = J.StyleNBodyEmulatorVelCore(mid_chan=mid)
+    xb = torch.from_numpy(x).cuda().to(torch.bfloat16)
+    d, v = model.apply(p, xb, np.array([OM]), np.atleast_1d(Dz), np.atleast_1d(vf))
+    assert d.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and d.is_cuda and tuple(d.shape) == (1, 3, d0 - 96, d1 - 96, d2 - 96)
+    # against the float32-equivalent result on the SAME bfloat16-rounded input: one bfloat16 rounding of the outputs (2^-9)
+    d32, v32 = model.apply(p, xb.float(), np.array([OM]), np.atleast_1d(Dz), np.atleast_1d(vf))
+    assert d32.dtype == torch.float32
+    assert torch.equal(d, d32.to(torch.bfloat16)) and torch.equal(v, v32.to(torch.bfloat16))
+    xh = torch.from_numpy(x).cuda().half()
+    dh, vh = model.apply(p, xh, np.array([OM]), np.atleast_1d(Dz), np.atleast_1d(vf))
+    assert dh.dtype == torch.float16 and rel_l2(dh.float().cpu().numpy()[0], GOLD[tag + "_disp"]) <= 2e-3
+
+
 def test_process_box_matches_golden_and_reference_semantics(precision):
     seed_p, seed_x, mid, s0, s1, s2, n0, n1, n2 = (int(v) for v in GOLD["pbox_meta"])
     p = _synthetic(seed_p, mid)
